@@ -1,0 +1,36 @@
+# Build the MI355X OFFT library (HIP kernels + C host) and the test oracle.
+#   make            -> offt_amd/liboffthip.so, oracle/liboracle.so
+#   make harness    -> bin/run-fft (C harness, links the HIP runtime explicitly)
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CC        ?= gcc
+ARCH      ?= gfx950
+CSRC      := offt_amd/csrc
+BUILD     := build
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude
+CFLAGS    := -std=gnu11 -O2 -g -Wall -Wextra -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude
+
+all: offt_amd/liboffthip.so oracle/liboracle.so
+
+$(BUILD):
+	mkdir -p $(BUILD)
+
+$(BUILD)/offt_kernels.o: $(CSRC)/offt_kernels.hip $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/kernel_resource_usage.txt || (cat $(BUILD)/kernel_resource_usage.txt; false)
+
+$(BUILD)/offt_host.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backend.h include/offt.h include/offt_hip.h | $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+# The HIP runtime is deliberately NOT a DT_NEEDED entry: the hosting process
+# decides which libamdhip64 is in use (PyTorch bundles its own); C programs link
+# -lamdhip64 themselves.
+offt_amd/liboffthip.so: $(BUILD)/offt_kernels.o $(BUILD)/offt_host.o
+	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lm -lpthread
+
+oracle/liboracle.so: oracle/oracle_fft.c oracle/oracle_offt.c oracle/oracle.h
+	$(CC) -std=gnu11 -O3 -fopenmp -fPIC -shared -Ioracle -o $@ oracle/oracle_fft.c oracle/oracle_offt.c -lm
+
+clean:
+	rm -rf $(BUILD) offt_amd/liboffthip.so oracle/liboracle.so bin
+
+.PHONY: all clean

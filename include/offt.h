@@ -1,0 +1,207 @@
+/*
+ * offt.h -- plan / execute API of the MI355X-native 3-D parallel FFT.
+ *
+ * Drop-in boundary: this header declares exactly the public surface of the
+ * reference's offt.h (rchyena/offt, offt.h:69-259, built with its Hopper flags
+ * -DA2AV -DSTRIDE and the in-header NOTEST switch), so that a caller such as
+ * the reference's run-fft.c compiles against it unchanged:
+ *
+ *   - struct _offt_params   (offt.h:69-100)   24 tunables + 3 status flags
+ *   - struct _offt_comm     (offt.h:102-142)  decomposition + i/o layout contract
+ *   - struct _offt_plan     (offt.h:144-233)  sizes, mode flags, timers, params, comm
+ *   - offt_3d_init / offt_3d_execute / offt_3d_fin / print_params /
+ *     offt_print_time       (offt.h:235-244), min/max inlines (offt.h:251-257)
+ *
+ * Same names, same argument meaning, same field names.  Members that were
+ * FFTW / MPI handles in the reference (fftw_plan, MPI_Comm*) are private there
+ * too and are opaque pointers here; no fftw3.h / mpi.h needed.
+ *
+ * Semantics kept: in-place (in == out), forward exp(-2 pi i ..), unnormalised,
+ * input addressed through comm->istart/isize/istride, output through
+ * comm->ostart/osize/ostride (offt-compute.c:246-313).  `in`/`out` may be host
+ * or device pointers (detected with hipPointerGetAttributes); device pointers
+ * stay resident and are the measured path.
+ */
+#ifndef OFFT_INCLUDE
+#define OFFT_INCLUDE
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUBTILE_SIZE (8192)
+#define NOTEST
+#define TUNING_REPS 1
+#define BUFFER_SIZE_LIMIT (32*1024*1024)
+
+/* FFTW planner flag values accepted (and ignored) by offt_3d_init, same
+ * numeric values as fftw3.h so existing callers pass them through unchanged. */
+#ifndef FFTW_MEASURE
+#define FFTW_FORWARD (-1)
+#define FFTW_BACKWARD (+1)
+#define FFTW_MEASURE (0U)
+#define FFTW_EXHAUSTIVE (1U << 3)
+#define FFTW_PATIENT (1U << 5)
+#define FFTW_ESTIMATE (1U << 6)
+#endif
+
+/* **********************************************************
+ @ structure for parameters  (reference offt.h:69-100)
+   ********************************************************** */
+struct _offt_params {
+  int is_converged;   /* 0:tuning not finished  1:finished */
+  int is_infeasible;  /* 0:params in a feasible area  1:infeasible area */
+  int is_in_database; /* 0:params not in a database file  1:in a database file */
+#define LOG0 (-1)
+#define _P1_ 0   /* decomposition factor p1: # processes on x dim (p = p1 x p2) */
+#define _T1_ 1   /* tile size in phase 1: # elements on x dim */
+#define _W1_ 2   /* window size in phase 1: max # tiles in flight */
+#define _Px1_ 3  /* CPU cache sub-tile sizes / MPI_Test frequencies: accepted, */
+#define _Py1_ 4  /* printed and stored like the reference, but they have no    */
+#define _Fz_ 5   /* effect on a GPU (LDS panel shapes are chosen by the static */
+#define _FP1_ 6  /* sweep; progress is stream-driven).                         */
+#define _Ux1_ 7
+#define _Uz1_ 8
+#define _FU1_ 9
+#define _Fy1_ 10
+#define _Ry_ 11  /* ratio of #ffty in phase I to total#ffty (0-10) */
+#define _T2_ 12  /* tile size in phase 2: # elements on z dim */
+#define _W2_ 13  /* window size in phase 2 */
+#define _Pz2_ 14
+#define _Px2_ 15
+#define _Fy2_ 16
+#define _FP2_ 17
+#define _Uz2_ 18
+#define _Uy2_ 19
+#define _FU2_ 20
+#define _Fx_ 21
+#define _V_ 22   /* 2-bit switch for A2AV leftbit:phase0, rightbit:phase1 */
+#define _S_ 23   /* switch for 1-D FFT method 0:TRANSPOSE 1:STRIDE */
+#define PARAM_COUNT 24
+  int v[PARAM_COUNT];
+};
+
+/* reference offt.h:102-142, A2AV layout */
+struct _offt_comm {
+  int p1;
+  int p2;
+  void *comm1;  /* row communicator (p2 ranks sharing rank_x); opaque   */
+  void *comm2;  /* column communicator (p1 ranks sharing rank_y); opaque */
+  void *group1;
+  void *group2;
+  int M1; /* ceil(Nx/p1) */
+  int M2; /* ceil(Ny/p2) */
+  int M3; /* ceil(Nz_new/p2) */
+  int M4; /* ceil(Ny/p1) */
+  int F1; /* floor(Nx/p1) */
+  int F2; /* floor(Ny/p2) */
+  int F3; /* floor(Nz_new/p2) */
+  int F4; /* floor(Ny/p1) */
+  int m1; /* # my elements on x */
+  int m2; /* # my elements on y during A2A1 */
+  int m3; /* # my elements on z */
+  int m4; /* # my elements on y during A2A2 */
+  int b1; /* # over-loaded nodes with floor(Nx/p1)+1 */
+  int b2;
+  int b3;
+  int b4;
+  int istart[3]; /* starting coodinates x,y,z */
+  int isize[3];  /* # elements on each dimenstion */
+  int istride[3]; /* memory stride amount (complex elements) */
+  int ostart[3];
+  int osize[3];
+  int ostride[3];
+};
+
+/* reference offt.h:144-233 */
+struct _offt_plan {
+  /* parameter-independent settings */
+  int p;
+  int rank;
+  int Nx;
+  int Ny;
+  int Nz;
+  int is_r2c;
+  int fftw_flag;
+  int ah_strategy;
+  int max_loop;
+  int tuning_mode;
+  int is_W0;
+  int extrapolation_window;
+  int is_oned;
+  int is_a2a;
+  int is_equalxy; /* output memory layout y-z-x when Nx == Ny */
+  int is_notest;
+#define INIT_ALL 0
+#define INIT_FFTW 1
+#define INIT_AH 2
+#define INIT_BUFFER 3
+#define T_INIT_COUNT 4
+  double t_init[T_INIT_COUNT];
+/* the timer array components */
+#define ALL 0
+#define INIT1 1
+#define WAIT1 2
+#define TEST1 3
+#define INIT2 4
+#define WAIT2 5
+#define TEST2 6
+#define FFTz 7
+#define FFTy1 8
+#define FFTy2 9
+#define FFTx 10
+#define TRANSPOSE 11
+#define PACK1 12
+#define UNPACK1 13
+#define PACK2 14
+#define UNPACK2 15
+#define GES 16
+  double t[GES];
+  char point_database_file[256];
+  char user_vertex_file[256];
+
+  /* parameter-dependent settings */
+  struct _offt_params *params;
+  struct _offt_comm *comm;
+  void *buffer_chunk;
+  void *buffers1;
+  void *buffers2;
+  void *pt_transpose;
+  void **pt_transpose_list;
+  int pt_transpose_list_size;
+  void *p1d_x;
+  void *p1d_y;
+  void *p1d_z;
+  void *p1d_x_t;
+  void *p1d_y_t;
+  void **p1d_x_s_list;
+  void **p1d_y_s_list;
+  int p1d_xy_s_list_size;
+  /* MI355X build: everything device-side (streams, events, tile rings, pass
+   * descriptors, RCCL communicators) hangs off this opaque pointer. */
+  void *hip_state;
+};
+
+struct _offt_plan* offt_3d_init(int Nx, int Ny, int Nz, double* in, double* out, int is_r2c, int fftw_flag, int is_oned, int is_a2a, int is_equalxy, int is_notest, int ah_strategy, int max_loop, int tuning_mode, int is_W0, int extrapolation_window, struct _offt_params *custom_params);
+void offt_3d_fin(struct _offt_plan *po);
+void offt_3d_execute(struct _offt_plan *po, double* in, double* out, int is_tuning);
+void print_params(int *v);
+void offt_print_time(double *t);
+
+#if !defined(__cplusplus) && !defined(OFFT_NO_MINMAX)
+#ifndef __GNUC__
+#define __inline__ inline
+#endif
+static __inline__ int max(int a, int b) {
+  return (a > b)?a:b;
+}
+
+static __inline__ int min(int a, int b) {
+  return (a < b)?a:b;
+}
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFFT_INCLUDE */

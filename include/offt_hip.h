@@ -1,0 +1,82 @@
+/*
+ * offt_hip.h -- MI355X-specific extensions around the offt.h boundary.
+ *
+ * The reference binds ranks through MPI_COMM_WORLD inside offt_3d_init
+ * (offt-compute.c:3315-3316) and exchanges tiles with MPI_Ialltoall
+ * (offt-compute.c:835-900).  Here one process drives one GPU and the exchange
+ * is an RCCL all-to-all over xGMI, so the world (rank, size, RCCL unique id) is
+ * handed in through this C ABI by whatever launcher is in use (torchrun +
+ * torch.distributed store, MPI_Bcast, a file): plain pointers and sizes only.
+ *
+ * Everything in this header is an extension: callers that only use offt.h get
+ * the reference's behaviour (single process == world of one rank).
+ */
+#ifndef OFFT_HIP_INCLUDE
+#define OFFT_HIP_INCLUDE
+
+#include "offt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFFT_HIP_UNIQUE_ID_BYTES 128
+
+/* ---- world bootstrap (replaces MPI_Comm_size/rank, offt-compute.c:3315) ---- */
+/* rank 0 creates the RCCL unique id; the launcher ships the 128 bytes around. */
+int offt_hip_get_unique_id(void *id128);
+/* declare this process as `rank` of `size`; id128 may be NULL when size == 1.
+ * Must precede offt_3d_init.  Binds the process to `device` (hipSetDevice).    */
+int offt_hip_set_world(int rank, int size, const void *id128, int device);
+/* tear the world down (destroys the RCCL communicator)                         */
+int offt_hip_finalize_world(void);
+int offt_hip_world_rank(void);
+int offt_hip_world_size(void);
+
+/* ---- plan extensions -------------------------------------------------------- */
+#define OFFT_HIP_F64 0
+#define OFFT_HIP_F32 1
+/* Same arguments as offt_3d_init plus the arithmetic type (the reference is
+ * double only, Appendix F of SURVEY.md).  With OFFT_HIP_F32 `in`/`out` point at
+ * interleaved float pairs.                                                      */
+struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, int is_r2c,
+                                   int fftw_flag, int is_oned, int is_a2a, int is_equalxy,
+                                   int is_notest, int ah_strategy, int max_loop, int tuning_mode,
+                                   int is_W0, int extrapolation_window,
+                                   struct _offt_params *custom_params, int precision);
+/* direction: -1 forward (what offt_3d_execute does), +1 inverse (unnormalised,
+ * FFTW_BACKWARD convention).  The inverse consumes the forward's OUTPUT layout
+ * (ostart/osize/ostride) and produces the INPUT layout (istart/isize/istride). */
+void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int direction);
+/* run on a caller-owned hipStream_t (NULL = the plan's own stream)             */
+void offt_hip_set_stream(struct _offt_plan *po, void *stream);
+/* 0: offt_3d_execute returns after the GPU finished (timers valid, reference
+ *    behaviour); 1: returns after enqueueing (caller synchronises the stream). */
+void offt_hip_set_async(struct _offt_plan *po, int async);
+/* select a static-sweep kernel variant per axis (0 = x, 1 = y, 2 = z); -1 default */
+void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant);
+/* bytes the caller must allocate for in/out on this rank (run-fft.c:294-304)   */
+long long offt_hip_local_bytes(const struct _offt_plan *po);
+/* device time of the last execute in seconds, from hipEvents on the plan stream */
+double offt_hip_last_device_seconds(const struct _offt_plan *po);
+/* per-pass device seconds of the last execute: z, y, x passes (0 if fused away) */
+void offt_hip_last_pass_seconds(const struct _offt_plan *po, double t[3]);
+/* last error text ("" if none); errors also go to stderr, like the reference's
+ * printf-only error handling (offt-compute.c:702-704)                           */
+const char *offt_hip_last_error(void);
+
+/* ---- device helpers for harnesses and tests ---------------------------------- */
+void *offt_hip_malloc(long long bytes);
+void offt_hip_free(void *p);
+int offt_hip_memcpy_h2d(void *dst, const void *src, long long bytes);
+int offt_hip_memcpy_d2h(void *dst, const void *src, long long bytes);
+int offt_hip_device_synchronize(void);
+/* fill this rank's input block (istart/isize/istride) on the device:
+ * kind 0 = harness ramp re = z + 10 y + 100 x (run-fft.c:46-61), 1 = seeded
+ * position hash in [-1,1)                                */
+int offt_hip_fill_input(struct _offt_plan *po, void *buf, int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

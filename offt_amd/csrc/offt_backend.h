@@ -1,0 +1,46 @@
+/*
+ * offt_backend.h -- the handful of device operations the host pipeline needs,
+ * as a table of C function pointers.  The library ships exactly ONE table:
+ * HIP kernels + HIP streams/events + RCCL (k_hip_backend in offt_host.c).
+ *
+ * offt_hip_test_set_backend() exists so that the CPU-only test-suite can run
+ * the real host logic (decomposition, pass descriptors, tile ring, exchange
+ * schedule) in world_size-2 `gloo` processes with a descriptor interpreter
+ * that lives under tests/ -- the library itself contains no CPU FFT and never
+ * installs another table on its own.
+ */
+#ifndef OFFT_BACKEND_H
+#define OFFT_BACKEND_H
+#include <stddef.h>
+#include "offt_hipk.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct offt_backend {
+  void *(*dmalloc)(size_t bytes);
+  void (*dfree)(void *p);
+  int (*prepare)(int n, int precision);
+  int (*pass)(const offt_pass_desc *d, const void *in, void *out, void *stream);
+  void *(*stream_create)(void);
+  void (*stream_destroy)(void *s);
+  void *(*event_create)(void);
+  void (*event_destroy)(void *e);
+  int (*event_record)(void *e, void *s);
+  int (*stream_wait)(void *s, void *e);
+  int (*stream_sync)(void *s);
+  double (*event_ms)(void *a, void *b);
+  /* all-to-all of one tile: which = 1 (row group, p2 peers) or 2 (column group,
+   * p1 peers); peer a sends sendbytes[a] from sendp[a], receives recvbytes[a]
+   * into recvp[a]; peer index == rank inside the group */
+  int (*a2a)(void *ctx, int which, int npeers, const int *peer, const void *const *sendp,
+             const size_t *sendbytes, void *const *recvp, const size_t *recvbytes, void *stream);
+  int (*memcpy_dd)(void *dst, const void *src, size_t bytes, void *stream);
+} offt_backend;
+
+void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+/*
+ * offt_hipk.h -- thin C ABI between the C host library (offt_host.c) and the
+ * hand-written HIP kernels (offt_kernels.hip).  Plain pointers and sizes only.
+ *
+ * One "pass" = a batch of 1-D FFTs of length n along one axis of a strided
+ * complex array, reading a panel [n x COLS] per workgroup, with independent
+ * input and output addressing so that the local transposes and the pack /
+ * unpack copies of the reference (offt-compute.c:905-2993, 523-653) are folded
+ * into the load / store side of the butterfly kernel instead of being separate
+ * sweeps over memory.
+ */
+#ifndef OFFT_HIPK_H
+#define OFFT_HIPK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFFT_PREC_F64 0
+#define OFFT_PREC_F32 1
+
+typedef struct offt_pass_desc {
+  int n;          /* FFT length along the axis                                   */
+  int precision;  /* OFFT_PREC_F64 / OFFT_PREC_F32                               */
+  int direction;  /* -1: forward exp(-2 pi i nk/N) (the reference's only mode),  */
+                  /* +1: inverse, unnormalised                                   */
+  int ncols;      /* number of columns (independent lines) per batch entry       */
+  int nb1, nb2;   /* two outer batch dimensions                                  */
+  /* all strides in complex elements */
+  long long in_axis_stride, in_col_stride, in_b1_stride, in_b2_stride;
+  long long out_axis_stride, out_col_stride, out_b1_stride, out_b2_stride;
+  /* optional split of the axis index into per-peer blocks (fused unpack on the
+   * load side / fused pack on the store side):
+   *   idx k -> (k / split) * block_stride + (k % split) * axis_stride
+   * split == 0 means "no split".  split_nfloor > 0 selects the reference's
+   * uneven A2AV partition (offt-compute.c:132-144): the first split_nfloor
+   * blocks hold `split` indices, the remaining ones `split + 1`.               */
+  int in_split, in_split_nfloor;
+  int out_split, out_split_nfloor;
+  long long in_block_stride, out_block_stride;
+  /* coalescing hints: 1 = the FFT axis is the unit-stride dimension,
+   *                   0 = the column dimension is the unit-stride dimension    */
+  int in_contig, out_contig;
+  int variant;    /* static-sweep variant id, -1 = default for this n           */
+  double scale;   /* multiplied into the output (1.0 = unnormalised)            */
+} offt_pass_desc;
+
+/* Build device twiddle tables etc. for length n; call at plan time (allocates). */
+int offt_hipk_prepare(int n, int precision);
+/* Launch one pass on `stream` (a hipStream_t).  No allocation, no sync.        */
+int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void *stream);
+/* 1 if a hand-tuned LDS/register Stockham kernel exists for (n, precision),
+ * 0 if the pass will run on the generic any-length kernel.                      */
+int offt_hipk_has_fast_path(int n, int precision);
+/* number of sweep variants registered for (n, precision, in_contig, out_contig) */
+int offt_hipk_variant_count(int n, int precision);
+/* human-readable description of a variant, for sweep logs                      */
+const char *offt_hipk_variant_name(int n, int precision, int variant);
+/* name of the kernel symbol a descriptor resolves to (for rocprof matching)    */
+const char *offt_hipk_kernel_name(const offt_pass_desc *d);
+/* strided complex copy / permutation (used for layouts no FFT pass can fold)   */
+int offt_hipk_copy3d(const void *in, void *out, int precision,
+                     int n0, int n1, int n2,
+                     long long is0, long long is1, long long is2,
+                     long long os0, long long os1, long long os2, void *stream);
+/* fill a local block with the seeded position hash / the harness ramp
+ * (run-fft.c:46-61); kind 0 = ramp, 1 = hash.                                   */
+int offt_hipk_fill(void *buf, int precision, int kind,
+                   int n0, int n1, int n2, int s0, int s1, int s2,
+                   long long st0, long long st1, long long st2, void *stream);
+const char *offt_hipk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
