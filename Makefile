@@ -34,3 +34,7 @@ clean:
 	rm -rf $(BUILD) offt_amd/liboffthip.so oracle/liboracle.so bin
 
 .PHONY: all clean
+
+# test-only CPU interpreter of pass descriptors (never linked into the product)
+tests/libcpubackend.so: tests/cpu_backend.c oracle/oracle_fft.c oracle/oracle.h offt_amd/csrc/offt_backend.h
+	$(CC) -std=gnu11 -O2 -fPIC -shared -Ioracle -Ioffamd -I$(CSRC) -o $@ tests/cpu_backend.c oracle/oracle_fft.c -lm

@@ -55,6 +55,9 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream);
 void offt_hip_set_async(struct _offt_plan *po, int async);
 /* select a static-sweep kernel variant per axis (0 = x, 1 = y, 2 = z); -1 default */
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant);
+/* multiply the result by `scale` in the store of the last pass (1.0 = the reference's
+ * unnormalised transform); free, it rides on the kernel's stores                  */
+void offt_hip_set_output_scale(struct _offt_plan *po, double scale);
 /* bytes the caller must allocate for in/out on this rank (run-fft.c:294-304)   */
 long long offt_hip_local_bytes(const struct _offt_plan *po);
 /* device time of the last execute in seconds, from hipEvents on the plan stream */

@@ -89,6 +89,8 @@ def lib():
     L.offt_hip_set_async.argtypes = [PP, i]
     L.offt_hip_set_variant.restype = None
     L.offt_hip_set_variant.argtypes = [PP, i, i]
+    L.offt_hip_set_output_scale.restype = None
+    L.offt_hip_set_output_scale.argtypes = [PP, C.c_double]
     L.offt_hip_local_bytes.restype = C.c_longlong
     L.offt_hip_local_bytes.argtypes = [PP]
     L.offt_hip_last_device_seconds.restype = C.c_double

@@ -322,6 +322,7 @@ typedef struct hip_state {
   ncclComm_t comm1, comm2; int have_comm1, have_comm2;
   void *stage; size_t stage_bytes;
   int variant[3];
+  double out_scale;
   int async;
   double last_dev_s, pass_s[3];
   int warned_in;
@@ -485,6 +486,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->esz = precision == OFFT_HIP_F64 ? 16 : 8;
   st->be = g_backend ? g_backend : &k_hip_backend;
   st->variant[0] = st->variant[1] = st->variant[2] = -1;
+  st->out_scale = 1.0;
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
   if (!g_backend) {
@@ -582,6 +584,7 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream) {
   if (stream) { st->s_compute = stream; st->own_stream = 0; }
   else { st->s_compute = st->be->stream_create(); st->own_stream = 1; }
 }
+void offt_hip_set_output_scale(struct _offt_plan *po, double scale) { ((hip_state *)po->hip_state)->out_scale = scale; }
 void offt_hip_set_async(struct _offt_plan *po, int async) { ((hip_state *)po->hip_state)->async = async; }
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
@@ -639,6 +642,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
       dx.out_axis_stride = os0; dx.out_col_stride = os2; dx.out_b1_stride = os1;
       dx.out_contig = (os0 == 1);
     }
+    dx.scale = st->out_scale;
     be->event_record(st->evp[0], s);
     if (be->pass(&dz, base, mid, s)) return -1;
     be->event_record(st->evp[1], s);
@@ -662,6 +666,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
     }
     dz.in_col_stride = ws1; dz.in_b1_stride = ws0;
     dz.out_col_stride = is1; dz.out_b1_stride = is0;
+    dz.scale = st->out_scale;
     be->event_record(st->evp[0], s);
     if (be->pass(&dx, base, mid, s)) return -1;
     be->event_record(st->evp[1], s);
@@ -798,6 +803,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     }
     d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
     d.out_contig = (c->ostride[0] == 1);
+    d.scale = st->out_scale;
     if (be->pass(&d, st->recv2, data, s)) return -1;
   }
   be->event_record(st->evp[3], s);

@@ -491,19 +491,31 @@ static double *scratch_for(const orc_world *w) {
   return (double *)malloc(sizeof(double) * 6 * (size_t)n + 64);
 }
 
-/* offt_3d_execute_phase1, offt-compute.c:3501-3680: tiles along x over comm1 */
+/* offt_3d_execute_phase1, offt-compute.c:3501-3680: tiles along x over comm1.
+ * All row groups advance tile by tile together (as concurrently running MPI
+ * ranks would); a rank whose group has fewer tiles simply sits a step out. */
 static void phase1(orc_world *w, int nthreads) {
   const int p1 = w->r[0].c.p1, p2 = w->r[0].c.p2, T = w->v[T1_];
-  (void)nthreads;
-  for (int rx = 0; rx < p1; rx++) {
-    const int m1 = w->r[rx * p2].c.m1, blocks = (m1 + T - 1) / T;
-    for (int i = 0; i < blocks; i++) {
+  int maxblocks = 0;
+  for (int rx = 0; rx < p1; rx++) maxblocks = imax(maxblocks, (w->r[rx * p2].c.m1 + T - 1) / T);
+  for (int i = 0; i < maxblocks; i++) {
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int k = 0; k < w->p; k++) {
+      const int m1 = w->r[k].c.m1, blocks = (m1 + T - 1) / T;
+      if (i >= blocks) continue;
       const int myT = (i == blocks - 1) ? m1 - (blocks - 1) * T : T; /* :3551-3552 */
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-      for (int j = 0; j < p2; j++) { double *scr = scratch_for(w); fftz_pack1(w, &w->r[rx * p2 + j], i, myT, scr); free(scr); }
-      a2a_phase1(w, rx, myT);
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-      for (int j = 0; j < p2; j++) { double *scr = scratch_for(w); unpack1_ffty(w, &w->r[rx * p2 + j], i, myT, scr); free(scr); }
+      double *scr = scratch_for(w); fftz_pack1(w, &w->r[k], i, myT, scr); free(scr);
+    }
+    for (int rx = 0; rx < p1; rx++) {
+      const int m1 = w->r[rx * p2].c.m1, blocks = (m1 + T - 1) / T;
+      if (i < blocks) a2a_phase1(w, rx, (i == blocks - 1) ? m1 - (blocks - 1) * T : T);
+    }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int k = 0; k < w->p; k++) {
+      const int m1 = w->r[k].c.m1, blocks = (m1 + T - 1) / T;
+      if (i >= blocks) continue;
+      const int myT = (i == blocks - 1) ? m1 - (blocks - 1) * T : T;
+      double *scr = scratch_for(w); unpack1_ffty(w, &w->r[k], i, myT, scr); free(scr);
     }
   }
 }
@@ -511,18 +523,29 @@ static void phase1(orc_world *w, int nthreads) {
 /* offt_3d_execute_phase2, offt-compute.c:3682-3862: tiles along z over comm2 */
 static void phase2(orc_world *w, int nthreads) {
   const int p1 = w->r[0].c.p1, p2 = w->r[0].c.p2, T = w->v[T2_];
-  (void)nthreads;
-  for (int ry = 0; ry < p2; ry++) {
-    const int m3 = w->r[ry].c.m3, blocks = (m3 + T - 1) / T;
-    for (int i = 0; i < blocks; i++) {
+  int maxblocks = 0;
+  for (int ry = 0; ry < p2; ry++) maxblocks = imax(maxblocks, (w->r[ry].c.m3 + T - 1) / T);
+  for (int i = 0; i < maxblocks; i++) {
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int k = 0; k < w->p; k++) {
+      const int m3 = w->r[k].c.m3, blocks = (m3 + T - 1) / T;
+      if (i >= blocks) continue;
       const int myT = (i == blocks - 1) ? m3 - (blocks - 1) * T : T;
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-      for (int j = 0; j < p1; j++) { double *scr = scratch_for(w); ffty_pack2(w, &w->r[j * p2 + ry], i, myT, scr); free(scr); }
-      a2a_phase2(w, ry, myT);
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-      for (int j = 0; j < p1; j++) { double *scr = scratch_for(w); unpack2_fftx(w, &w->r[j * p2 + ry], i, myT, scr); free(scr); }
+      double *scr = scratch_for(w); ffty_pack2(w, &w->r[k], i, myT, scr); free(scr);
+    }
+    for (int ry = 0; ry < p2; ry++) {
+      const int m3 = w->r[ry].c.m3, blocks = (m3 + T - 1) / T;
+      if (i < blocks) a2a_phase2(w, ry, (i == blocks - 1) ? m3 - (blocks - 1) * T : T);
+    }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int k = 0; k < w->p; k++) {
+      const int m3 = w->r[k].c.m3, blocks = (m3 + T - 1) / T;
+      if (i >= blocks) continue;
+      const int myT = (i == blocks - 1) ? m3 - (blocks - 1) * T : T;
+      double *scr = scratch_for(w); unpack2_fftx(w, &w->r[k], i, myT, scr); free(scr);
     }
   }
+  (void)p1;
 }
 
 /* offt_3d_execute, offt-compute.c:3864-4048 */
@@ -557,7 +580,10 @@ void orc_world_execute(orc_world *w, int nthreads) {
     phase2(w, nthreads);
   } else { /* mode C, :3999-4036 */
     phase1(w, nthreads);
-    if (!S) for (int k = 0; k < w->p; k++) transpose_local(w, &w->r[k]);
+    if (!S) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+      for (int k = 0; k < w->p; k++) transpose_local(w, &w->r[k]);
+    }
     phase2(w, nthreads);
   }
 }

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the product library and the oracle are built (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    need = [os.path.join(ROOT, "offt_amd", "liboffthip.so"), os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "tests", "libcpubackend.so")]
+    if not all(os.path.exists(n) for n in need):
+        subprocess.check_call(["make", "-C", ROOT, "all", "tests/libcpubackend.so"])
+    return True

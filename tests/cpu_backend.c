@@ -1,0 +1,85 @@
+/*
+ * cpu_backend.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A CPU interpreter of offt_pass_desc plus host-memory "streams", installed
+ * through offt_hip_test_set_backend() so that the CPU-only test-suite can run
+ * the product's real host logic (decomposition, pass descriptors, tile ring,
+ * exchange schedule of offt_host.c) without a GPU, including world_size-2
+ * `gloo` runs where the all-to-all is a Python callback.  It is built into
+ * tests/libcpubackend.so, never into offt_amd/liboffthip.so.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "offt_backend.h"
+#include "oracle.h"
+
+typedef int (*a2a_cb_t)(int which, int npeers, const void *const *sendp, const size_t *sendbytes,
+                        void *const *recvp, const size_t *recvbytes);
+static a2a_cb_t g_a2a_cb = NULL;
+static long g_pass_count = 0;
+
+static void *cb_malloc(size_t b) { return calloc(1, b ? b : 16); }
+static void cb_free(void *p) { free(p); }
+static int cb_prepare(int n, int prec) { (void)n; (void)prec; return 0; }
+
+static long long split_off(int k, int split, int nfloor, long long blk, long long axis) {
+  if (split == 0 && nfloor == 0) return (long long)k * axis;
+  int a, r;
+  if (nfloor > 0 && k >= split * nfloor) { int kk = k - split * nfloor; a = nfloor + kk / (split + 1); r = kk % (split + 1); }
+  else { a = k / split; r = k % split; }
+  return (long long)a * blk + (long long)r * axis;
+}
+
+static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *stream) {
+  (void)stream;
+  g_pass_count++;
+  if (d->n < 1 || d->ncols < 1 || d->nb1 < 1 || d->nb2 < 1) return 0;
+  const int n = d->n, f32 = d->precision == OFFT_PREC_F32;
+  orc_fft_plan *pl = orc_fft_plan_create(n);
+  double *line = (double *)malloc(sizeof(double) * 2 * (size_t)n), *scr = (double *)malloc(sizeof(double) * 6 * (size_t)n + 64);
+  for (int b2 = 0; b2 < d->nb2; b2++)
+    for (int b1 = 0; b1 < d->nb1; b1++)
+      for (int c = 0; c < d->ncols; c++) {
+        long long ib = (long long)b1 * d->in_b1_stride + (long long)b2 * d->in_b2_stride + (long long)c * d->in_col_stride;
+        long long ob = (long long)b1 * d->out_b1_stride + (long long)b2 * d->out_b2_stride + (long long)c * d->out_col_stride;
+        for (int k = 0; k < n; k++) {
+          long long o = ib + split_off(k, d->in_split, d->in_split_nfloor, d->in_block_stride, d->in_axis_stride);
+          double re, im;
+          if (f32) { re = ((const float *)in)[2 * o]; im = ((const float *)in)[2 * o + 1]; }
+          else { re = ((const double *)in)[2 * o]; im = ((const double *)in)[2 * o + 1]; }
+          line[2 * k] = re; line[2 * k + 1] = d->direction > 0 ? -im : im;
+        }
+        orc_fft_execute(pl, line, 1, 0, 1, scr);
+        for (int k = 0; k < n; k++) {
+          long long o = ob + split_off(k, d->out_split, d->out_split_nfloor, d->out_block_stride, d->out_axis_stride);
+          double re = line[2 * k] * d->scale, im = (d->direction > 0 ? -line[2 * k + 1] : line[2 * k + 1]) * d->scale;
+          if (f32) { ((float *)out)[2 * o] = (float)re; ((float *)out)[2 * o + 1] = (float)im; }
+          else { ((double *)out)[2 * o] = re; ((double *)out)[2 * o + 1] = im; }
+        }
+      }
+  free(line); free(scr); orc_fft_plan_destroy(pl);
+  return 0;
+}
+static void *cb_stream_create(void) { return malloc(8); }
+static void cb_stream_destroy(void *s) { free(s); }
+static void *cb_event_create(void) { return malloc(8); }
+static void cb_event_destroy(void *e) { free(e); }
+static int cb_event_record(void *e, void *s) { (void)e; (void)s; return 0; }
+static int cb_stream_wait(void *s, void *e) { (void)e; (void)s; return 0; }
+static int cb_stream_sync(void *s) { (void)s; return 0; }
+static double cb_event_ms(void *a, void *b) { (void)a; (void)b; return 0.0; }
+static int cb_a2a(void *ctx, int which, int npeers, const int *peer, const void *const *sendp, const size_t *sendbytes,
+                  void *const *recvp, const size_t *recvbytes, void *stream) {
+  (void)ctx; (void)peer; (void)stream;
+  if (!g_a2a_cb) return -1;
+  return g_a2a_cb(which, npeers, sendp, sendbytes, recvp, recvbytes);
+}
+static int cb_memcpy_dd(void *dst, const void *src, size_t bytes, void *s) { (void)s; memmove(dst, src, bytes); return 0; }
+
+static const offt_backend k_cpu_backend = {cb_malloc, cb_free, cb_prepare, cb_pass, cb_stream_create, cb_stream_destroy,
+                                           cb_event_create, cb_event_destroy, cb_event_record, cb_stream_wait,
+                                           cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd};
+
+const offt_backend *cpu_backend_table(void) { return &k_cpu_backend; }
+void cpu_backend_set_a2a(a2a_cb_t cb) { g_a2a_cb = cb; }
+long cpu_backend_pass_count(void) { return g_pass_count; }

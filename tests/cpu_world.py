@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE: run the product's host logic (liboffthip.so) on the test-only CPU backend.
+
+Single process: the all-to-all callback copies blocks locally (world of one rank).
+Multi process: one `gloo` rank per process, the callback exchanges blocks with isend/irecv.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_lib as O
+from offt_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A2A_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+_keep = {}
+
+
+def _cb_lib():
+    so = os.path.join(ROOT, "tests", "libcpubackend.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", ROOT, "tests/libcpubackend.so"])
+    L = C.CDLL(so)
+    L.cpu_backend_table.restype = C.c_void_p
+    L.cpu_backend_pass_count.restype = C.c_long
+    return L
+
+
+def install(rank=0, size=1, p1=None, dist=None):
+    """Install the CPU backend into liboffthip.so for (rank, size)."""
+    CB = _cb_lib()
+    L = api.lib()
+    L.offt_hip_test_set_backend.argtypes = [C.c_void_p, C.c_int, C.c_int]
+
+    def a2a(which, npeers, sendp, sendbytes, recvp, recvbytes):
+        try:
+            import torch
+            p2 = size // p1 if p1 else size
+            rx, ry = rank // p2, rank % p2
+            reqs, keep = [], []
+            for a in range(npeers):
+                peer = rx * p2 + a if which == 1 else a * p2 + ry
+                sb, rb = sendbytes[a], recvbytes[a]
+                if peer == rank:
+                    assert sb == rb
+                    C.memmove(recvp[a], sendp[a], sb)
+                    continue
+                if rb:
+                    buf = (C.c_char * rb).from_address(recvp[a])
+                    t = torch.frombuffer(buf, dtype=torch.uint8)
+                    keep.append(t)
+                    reqs.append(dist.irecv(t, src=peer, tag=which))
+                if sb:
+                    buf = (C.c_char * sb).from_address(sendp[a])
+                    t = torch.frombuffer(buf, dtype=torch.uint8)
+                    keep.append(t)
+                    reqs.append(dist.isend(t, dst=peer, tag=which))
+            for r in reqs:
+                r.wait()
+            return 0
+        except Exception as e:  # surfaced as a failed execute
+            print("a2a callback failed:", repr(e), flush=True)
+            return -1
+
+    cb = A2A_CB(a2a)
+    _keep["cb"] = cb
+    _keep["lib"] = CB
+    CB.cpu_backend_set_a2a(cb)
+    L.offt_hip_test_set_backend(CB.cpu_backend_table(), rank, size)
+    return CB
+
+
+def uninstall():
+    L = api.lib()
+    L.offt_hip_test_set_backend.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.offt_hip_test_set_backend(None, 0, 1)
+
+
+def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, **params):
+    """init + fill this rank's block on the host + execute; returns (comm dict, params, local result array)."""
+    cp = api.make_params(**params)
+    po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision)
+    c = api.comm_dict(po)
+    v = list(po.contents.params.contents.v)
+    n = api.local_elems(po)
+    ct = np.complex128 if precision == api.F64 else np.complex64
+    buf = np.zeros(n, dtype=ct)
+    i0, i1, i2 = c["isize"]
+    if i0 and i1 and i2:
+        f = O.hash_field(i0, i1, i2, c["istart"][0], c["istart"][1], c["istart"][2]) if kind else \
+            O.ramp_field(Nx, Ny, Nz)[c["istart"][0]:c["istart"][0] + i0, c["istart"][1]:c["istart"][1] + i1, :]
+        s0, s1, s2 = c["istride"]
+        idx = np.arange(i0)[:, None, None] * s0 + np.arange(i1)[None, :, None] * s1 + np.arange(i2)[None, None, :] * s2
+        buf[idx.ravel()] = f.astype(ct).ravel()
+    ptr = buf.ctypes.data_as(C.c_void_p)
+    api.offt_3d_execute_dir(po, ptr, ptr, direction)
+    api.offt_3d_fin(po)
+    return c, v, buf
+
+
+def scatter_out(c, buf, G):
+    """place a rank's output block (ostart/osize/ostride) into the global array G."""
+    o0, o1, o2 = c["osize"]
+    if not (o0 and o1 and o2):
+        return
+    s0, s1, s2 = c["ostride"]
+    idx = np.arange(o0)[:, None, None] * s0 + np.arange(o1)[None, :, None] * s1 + np.arange(o2)[None, None, :] * s2
+    G[c["ostart"][0]:c["ostart"][0] + o0, c["ostart"][1]:c["ostart"][1] + o1, c["ostart"][2]:c["ostart"][2] + o2] = \
+        buf[idx.ravel()].reshape(o0, o1, o2)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Regenerate the committed golden fixtures (run in the development container).
+
+1. ref_n18_p6_p1-2_S1.npz -- OUTPUT OF THE REFERENCE ITSELF: the survey stage
+   compiled the unmodified rchyena/offt sources against MPICH + MKL's FFTW3
+   wrapper symbols and ran `mpiexec -n 6 ./dump 18 2 0 1` (SURVEY.md Appendix D
+   step 5: N=18, p1=2, is_equalxy=0, S=1, seeded position-hash input).  Each
+   rank dumped `gx gy gz re im` through ostart/osize/ostride into
+   /tmp/oracle/out.<rank>.txt; this script only repackages those text files
+   (data, no reference source) together with their `# ostart.. osize.. ostride..`
+   header lines.  It does not run or build the reference.
+2. survey_recorded.json -- values the survey recorded from reference runs
+   (BASELINE.md 2): default-parameter line for N=128 p=2, the
+   run-fft -v spot values at 128^3 on 2 ranks, and the default P1 choices.
+3. numpy_fftn_*.npz -- independent second oracle: numpy.fft.fftn (pocketfft) of
+   the seeded hash field for 8^3, 16^3 and 20^3.
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402  (hash_field only)
+
+
+def ref_dump(src="/tmp/oracle"):
+    files = sorted(glob.glob(os.path.join(src, "out.*.txt")))
+    if len(files) != 6:
+        print("survey dump not present; keeping the committed fixture")
+        return
+    coords, vals, layout = [], [], []
+    for r, fn in enumerate(files):
+        h = open(fn).readline().split()
+        layout.append([int(x) for x in h[2:5] + h[6:9] + h[10:13]])
+        d = np.loadtxt(fn, ndmin=2)
+        coords.append(np.concatenate([np.full((len(d), 1), r), d[:, :3]], axis=1).astype(np.int16))
+        vals.append(d[:, 3] + 1j * d[:, 4])
+    np.savez_compressed(os.path.join(HERE, "ref_n18_p6_p1-2_S1.npz"), rank_xyz=np.concatenate(coords),
+                        value=np.concatenate(vals), ostart_osize_ostride=np.array(layout, dtype=np.int32))
+
+
+def survey_values():
+    rec = {
+        "source": "SURVEY.md 8(c) fixtures row, BASELINE.md section 2 (reference run in the survey container)",
+        "default_params_N128_p2": {"P1": 1, "T1": 8, "W1": 2, "Px1": 8, "Py1": 8, "Fz": 1, "FP1": 1, "Ux1": 8,
+                                    "Uz1": 8, "FU1": 1, "Fy1": 1, "Ry": 5, "T2": 4, "W2": 2, "Pz2": 4, "Px2": 16,
+                                    "Fy2": 0, "FP2": 0, "Uz2": 4, "Uy2": 16, "FU2": 0, "Fx": 0, "V": 0, "S": 0},
+        "default_P1": {"8": 2, "2": 1},
+        "ramp_128_p2_X000": 14781775872.0,
+        "ramp_closed_form": "X[0,0,0]=N^3*111*(N-1)/2 ; X[0,0,k]=N^3*(-1/2 + (i/2)cot(pi k/N)), k != 0",
+        "layout_1024_p8_2x4": {"M1": 512, "M2": 256, "M3": 256, "M4": 512, "istride": [262144, 1024, 1],
+                               "ostride_zyx": [1, 1024, 524288]},
+    }
+    json.dump(rec, open(os.path.join(HERE, "survey_recorded.json"), "w"), indent=1)
+
+
+def numpy_goldens():
+    for n in (8, 16, 20):
+        f = O.hash_field(n, n, n)
+        np.savez_compressed(os.path.join(HERE, f"numpy_fftn_hash_{n}.npz"), F=np.fft.fftn(f))
+
+
+if __name__ == "__main__":
+    ref_dump()
+    survey_values()
+    numpy_goldens()
+    print("fixtures written to", HERE)

@@ -1,0 +1,46 @@
+"""helpers for the -m gpu parity tests: everything goes through the C ABI (offt_amd.api)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_lib as O
+from offt_amd import api
+
+
+def make_input(po, field, precision=api.F64):
+    """host array in this rank's input layout (istart/isize/istride) -> device tensor"""
+    c = api.comm_dict(po)
+    ct = np.complex128 if precision == api.F64 else np.complex64
+    buf = np.zeros(api.local_elems(po), dtype=ct)
+    s0, s1, s2 = c["istride"]
+    n0, n1, n2 = field.shape
+    idx = (np.arange(n0)[:, None, None] * s0 + np.arange(n1)[None, :, None] * s1 + np.arange(n2)[None, None, :] * s2).ravel()
+    buf[idx] = field.astype(ct).ravel()
+    dev = torch.from_numpy(buf.view(np.float64 if precision == api.F64 else np.float32)).cuda()
+    return dev, idx
+
+
+def read_output(po, dev, shape, precision=api.F64):
+    c = api.comm_dict(po)
+    ct = np.complex128 if precision == api.F64 else np.complex64
+    res = dev.cpu().numpy().view(ct)
+    s0, s1, s2 = c["ostride"]
+    n0, n1, n2 = shape
+    idx = (np.arange(n0)[:, None, None] * s0 + np.arange(n1)[None, :, None] * s1 + np.arange(n2)[None, None, :] * s2).ravel()
+    return res[idx].reshape(shape)
+
+
+def gpu_fft(shape, field=None, is_equalxy=0, precision=api.F64, **params):
+    field = O.hash_field(*shape) if field is None else field
+    po = api.offt_3d_init(*shape, custom_params=api.make_params(**params), is_equalxy=is_equalxy, precision=precision)
+    try:
+        dev, _ = make_input(po, field, precision)
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        return read_output(po, dev, shape, precision), api.comm_dict(po)
+    finally:
+        api.offt_3d_fin(po)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)

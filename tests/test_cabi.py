@@ -1,0 +1,70 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/*.h declares.
+No compute calls here."""
+import ctypes as C
+import os
+import re
+
+from offt_amd import _lib, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"static __inline__ int (max|min)\(.*?\n}", "", txt, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}()]*(?:\([^()]*\)[^;{}()]*)*\)\s*;", txt)
+    return sorted(set(n for n in names if n.startswith(("offt_", "print_params"))))
+
+
+def test_library_loads_and_exports_everything(built):
+    L = _lib.load()
+    want = declared_functions("offt.h") + declared_functions("offt_hip.h")
+    assert {"offt_3d_init", "offt_3d_execute", "offt_3d_fin", "print_params", "offt_print_time"} <= set(want)
+    assert len(want) >= 20
+    missing = [n for n in want if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_dt_needed_on_hip_and_no_oracle_symbols(built):
+    """the product library must not pull in the oracle, and leaves the HIP runtime choice to the host process"""
+    import subprocess
+    out = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
+    assert "liboracle" not in out
+    syms = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    assert "orc_" not in syms
+
+
+def test_struct_mirror_sizes(built):
+    # the ctypes mirror must agree with the C layout: compile-time facts only
+    assert C.sizeof(api.OfftParams) == 4 * 27
+    assert api.OfftComm.M1.offset == 8 + 4 * 8
+    assert api.OfftPlan.t.offset % 8 == 0
+
+
+def test_print_formats(built, capfd):
+    """stdout formats the reference harness relies on (offt-compute.c:3239-3294)"""
+    L = api.lib()
+    v = (C.c_int * 24)(*range(24))
+    v[3] = -1
+    L.print_params(v)
+    t = (C.c_double * 16)(*[i / 8 for i in range(16)])
+    L.offt_print_time(t)
+    C.CDLL(None).fflush(None)
+    out = capfd.readouterr().out.splitlines()
+    assert out[0] == "P1 0 T1 1 W1 2 Py1 4 Fz 5 FP1 6 Ux1 7 Uz1 8 FU1 9 Fy1 10 Ry 11 T2 12 W2 13 Pz2 14 Px2 15 Fy2 16 FP2 17 Uz2 18 Uy2 19 FU2 20 Fx 21 V 22 S 23 "
+    assert out[1] == "0.00000  0.12500 0.25000 0.37500 0.50000 0.62500 0.75000  1.37500  1.50000 1.62500 1.75000 1.87500  0.87500 1.00000 1.12500 1.25000"
+
+
+def test_fails_loudly_without_gpu(built):
+    """no CPU fallback: without a HIP device init must refuse (skipped where a GPU exists)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    try:
+        api.offt_3d_init(8, 8, 8)
+    except RuntimeError as e:
+        assert "no HIP device" in str(e) or "hip" in str(e).lower()
+    else:
+        raise AssertionError("offt_3d_init succeeded without a GPU")

@@ -1,0 +1,205 @@
+"""-m gpu: the HIP path, called through the C ABI, against the oracle (CPU restatement of the
+reference), the committed golden fixtures and size-independent properties at full size.
+
+Tolerances (BASELINE.md 4 / SURVEY.md 8d): double rel-L2 <= 1e-13 and max-abs/max <= 1e-12;
+single rel-L2 <= 5e-6."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from gpu_util import gpu_fft, make_input, read_output, rel
+from offt_amd import api
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL64, TOLMAX64, TOL32 = 1e-13, 1e-12, 5e-6
+
+
+def check64(got, want):
+    assert rel(got, want) <= TOL64
+    assert np.abs(got - want).max() / np.abs(want).max() <= TOLMAX64
+
+
+LAYOUTS = [dict(S=1), dict(), dict(eq=1)]
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128])
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_cube_vs_oracle(built, n, layout):
+    eq = layout.get("eq", 0)
+    params = {k: v for k, v in layout.items() if k != "eq"}
+    got, c = gpu_fft((n, n, n), is_equalxy=eq, **params)
+    want, comms, _ = O.world_fft(n, n, n, 1, kind=1, is_equalxy=eq, **params)
+    check64(got, want)
+    oc = comms[0]
+    for k in ("istart", "isize", "istride", "ostart", "osize", "ostride", "M1", "M2", "M3", "M4"):
+        assert c[k] == oc[k], k
+
+
+@pytest.mark.parametrize("n", [8, 16, 20])
+def test_numpy_golden_fixtures(built, n):
+    F = np.load(os.path.join(G, f"numpy_fftn_hash_{n}.npz"))["F"]
+    for layout in LAYOUTS:
+        eq = layout.get("eq", 0)
+        got, _ = gpu_fft((n, n, n), is_equalxy=eq, **{k: v for k, v in layout.items() if k != "eq"})
+        check64(got, F)
+
+
+def test_reference_dump_fixture(built):
+    """the compiled reference's own full-grid output (18^3, survey run) -- any decomposition gives the same X[k]"""
+    d = np.load(os.path.join(G, "ref_n18_p6_p1-2_S1.npz"))
+    ref = np.zeros((18, 18, 18), dtype=complex)
+    r = d["rank_xyz"].astype(int)
+    ref[r[:, 1], r[:, 2], r[:, 3]] = d["value"]
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft((18, 18, 18), **layout)
+        check64(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 16), (16, 128, 64), (256, 8, 4), (4, 512, 8), (8, 4, 1024), (2048, 4, 4),
+                                   (4, 4, 4096), (2, 2, 2), (4, 2, 8)])
+def test_non_cubic_pow2(built, shape):
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft(shape, **layout)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)
+        check64(got, want)
+
+
+@pytest.mark.parametrize("shape", [(20, 20, 20), (18, 12, 30), (7, 5, 3), (1, 9, 1), (1, 1, 1), (100, 3, 6), (3, 96, 50)])
+def test_any_length_generic_kernel(built, shape):
+    """lengths without a Stockham fast path (FFTW accepts any N): generic kernel, same tolerance"""
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft(shape, **layout)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)
+        check64(got, want)
+
+
+def test_ramp_closed_form_spot_values(built):
+    """run-fft -v prints out[0,0,0..3]; for the ramp these have a closed form"""
+    rec = json.load(open(os.path.join(G, "survey_recorded.json")))
+    for n in (128, 256):
+        got, _ = gpu_fft((n, n, n), field=O.ramp_field(n, n, n))
+        assert got[0, 0, 0].real == n ** 3 * 111 * (n - 1) / 2 and got[0, 0, 0].imag == 0
+        k = np.arange(1, 4)
+        cf = n ** 3 * (-0.5 + 0.5j / np.tan(np.pi * k / n))
+        assert np.abs(got[0, 0, 1:4] - cf).max() / np.abs(cf).max() < 1e-13
+        if n == 128:
+            assert got[0, 0, 0].real == rec["ramp_128_p2_X000"]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_forward_inverse_roundtrip_512(built, layout):
+    """BASELINE config[1]: 512^3 double-complex forward + inverse on one MI355X"""
+    n = 512
+    eq = layout.get("eq", 0)
+    po = api.offt_3d_init(n, n, n, custom_params=api.make_params(**{k: v for k, v in layout.items() if k != "eq"}),
+                          is_equalxy=eq)
+    L = api.lib()
+    dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64, device="cuda")
+    L.offt_hip_fill_input(po, dev.data_ptr(), 1)
+    x0 = dev.clone()
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    # Parseval on the forward result
+    e_in, e_out = float((x0 * x0).sum()), float((dev * dev).sum())
+    assert abs(e_out / n ** 3 - e_in) / e_in < 1e-13
+    api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+    dev /= n ** 3
+    err = float(torch.linalg.vector_norm(dev - x0) / torch.linalg.vector_norm(x0))
+    api.offt_3d_fin(po)
+    assert err < TOL64
+
+
+def test_full_size_1024_properties(built):
+    """1024^3 double-complex (BASELINE config[2]): closed-form ramp spots + Parseval + linearity probe"""
+    n = 1024
+    po = api.offt_3d_init(n, n, n)
+    L = api.lib()
+    c = api.comm_dict(po)
+    dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64, device="cuda")
+    L.offt_hip_fill_input(po, dev.data_ptr(), 0)  # harness ramp
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    cv = torch.view_as_complex(dev.view(-1, 2))
+    os0, os1, os2 = c["ostride"]
+    assert complex(cv[0]) == n ** 3 * 111 * (n - 1) / 2
+    for k in (1, 2, 3, 511):
+        cf = n ** 3 * (-0.5 + 0.5j / np.tan(np.pi * k / n))
+        assert abs(complex(cv[k * os2]) - cf) / abs(cf) < 1e-12   # X[0,0,k]
+        assert abs(complex(cv[k * os1]) - 10 * cf) / abs(10 * cf) < 1e-12  # X[0,k,0] = 10 * ...
+        assert abs(complex(cv[k * os0]) - 100 * cf) / abs(100 * cf) < 1e-12
+    # everything off the three axes is zero for a separable ramp
+    assert abs(complex(cv[os0 + os1 + os2])) / n ** 3 < 1e-9
+    L.offt_hip_fill_input(po, dev.data_ptr(), 1)
+    e_in = float((dev * dev).sum())
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    e_out = float((dev * dev).sum())
+    api.offt_3d_fin(po)
+    assert abs(e_out / n ** 3 - e_in) / e_in < 1e-13
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_single_precision(built, n):
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft((n, n, n), precision=api.F32, **layout)
+        want = np.fft.fftn(O.hash_field(n, n, n).astype(np.complex64).astype(np.complex128))
+        assert rel(got.astype(np.complex128), want) <= TOL32
+
+
+def test_linearity_and_shift(built):
+    n = 64
+    f, g = O.hash_field(n, n, n), O.hash_field(n, n, n, 7, 11, 13)
+    F, _ = gpu_fft((n, n, n), field=f)
+    Gq, _ = gpu_fft((n, n, n), field=g)
+    H, _ = gpu_fft((n, n, n), field=2.5 * f - 1j * g)
+    assert rel(H, 2.5 * F - 1j * Gq) < TOL64
+    # circular shift theorem along z
+    Fs, _ = gpu_fft((n, n, n), field=np.roll(f, 3, axis=2))
+    k = np.arange(n)
+    assert rel(Fs, F * np.exp(-2j * np.pi * 3 * k / n)[None, None, :]) < TOL64
+
+
+def test_forced_tile_pipeline_on_one_gpu(built, monkeypatch):
+    """the multi-rank code path (tile ring, fused pack/unpack descriptors, streams/events) with p = 1"""
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    for shape, kw in [((64, 64, 64), dict(T1=4, W1=2)), ((32, 16, 64), dict(T1=5, W1=1, S=1)), ((20, 12, 18), dict(T1=3, W1=0)),
+                      ((128, 128, 128), dict())]:
+        got, _ = gpu_fft(shape, **kw)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **kw)
+        check64(got, want)
+
+
+def test_host_pointer_boundary(built):
+    """the reference hands over a calloc'ed host array (run-fft.c:304): staged through HBM"""
+    n = 32
+    po = api.offt_3d_init(n, n, n)
+    f = O.hash_field(n, n, n)
+    buf = np.ascontiguousarray(f.ravel())
+    p = buf.ctypes.data_as(C.c_void_p)
+    api.offt_3d_execute(po, p, p)
+    c = api.comm_dict(po)
+    api.offt_3d_fin(po)
+    s0, s1, s2 = c["ostride"]
+    idx = (np.arange(n)[:, None, None] * s0 + np.arange(n)[None, :, None] * s1 + np.arange(n)[None, None, :] * s2).ravel()
+    check64(buf[idx].reshape(n, n, n), np.fft.fftn(f))
+
+
+def test_sweep_variants_agree(built):
+    L = api.lib()
+    n = 1024
+    shape = (n, 8, 8)
+    base, _ = gpu_fft(shape)
+    nv = L.offt_hipk_variant_count(n, 0)
+    assert nv >= 2
+    for v in range(nv):
+        po = api.offt_3d_init(*shape)
+        for ax in range(3):
+            L.offt_hip_set_variant(po, ax, v)
+        dev, _ = make_input(po, O.hash_field(*shape))
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        got = read_output(po, dev, shape)
+        api.offt_3d_fin(po)
+        assert rel(got, base) < 1e-15 * 10
