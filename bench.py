@@ -96,6 +96,7 @@ def main():
     c = api.comm_dict(po)
     nel = api.local_elems(po)
     data = torch.zeros(nel * 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()  # the plan owns a non-blocking stream: order it after torch's zero fill
     L.offt_hip_fill_input(po, data.data_ptr(), 1)  # seeded position hash in [-1, 1)
     # keep magnitudes bounded over many back-to-back transforms: exact power-of-two rescale in the last store
     L.offt_hip_set_output_scale(po, 2.0 ** -(round(math.log2(E)) // 2))

@@ -323,8 +323,10 @@ typedef struct hip_state {
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
+  int zchunk;
   int async;
   double last_dev_s, pass_s[3];
+  int pass_slot[3];
   int warned_in;
 } hip_state;
 
@@ -337,7 +339,9 @@ static void *hb_malloc(size_t bytes) {
 }
 static void hb_free(void *p) { if (p) (void)hipFree(p); }
 static int hb_pass(const offt_pass_desc *d, const void *in, void *out, void *stream) {
-  return offt_hipk_fft_pass(d, in, out, stream);
+  int rc = offt_hipk_fft_pass(d, in, out, stream);
+  if (rc) SET_ERR("pass n=%d failed: %s", d->n, offt_hipk_last_error());
+  return rc;
 }
 static int hb_prepare(int n, int prec) { return offt_hipk_prepare(n, prec); }
 static void *hb_stream_create(void) {
@@ -357,7 +361,10 @@ static int hb_stream_wait(void *s, void *e) { HCHECK(hipStreamWaitEvent((hipStre
 static int hb_stream_sync(void *s) { HCHECK(hipStreamSynchronize((hipStream_t)s), return -1); return 0; }
 static double hb_event_ms(void *a, void *b) {
   float ms = 0;
-  if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return 0;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) {
+    (void)hipGetLastError(); /* an event of a pass that did not run: not an error, clear the sticky code */
+    return 0;
+  }
   return ms;
 }
 /* all-to-all of one tile inside a row/column group (communicate_a2a(v),
@@ -487,6 +494,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->be = g_backend ? g_backend : &k_hip_backend;
   st->variant[0] = st->variant[1] = st->variant[2] = -1;
   st->out_scale = 1.0;
+  st->zchunk = getenv("OFFT_ZCHUNK") ? atoi(getenv("OFFT_ZCHUNK")) : 0;
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
   if (!g_backend) {
@@ -607,74 +615,136 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   const long long is0 = c->istride[0], is1 = c->istride[1];
   const long long os0 = c->ostride[0], os1 = c->ostride[1], os2 = c->ostride[2];
   void *s = st->s_compute;
-  char *base = (char *)data;
-  offt_pass_desc dz, dy, dx;
-  const int in_place = po->params->v[_S_] != 0;
-  void *mid = in_place ? data : st->work; /* [x][y][z] natural layout, row Nz */
-  const long long ws1 = in_place ? is1 : Nz, ws0 = in_place ? is0 : (long long)Ny * Nz;
+  void *W = st->work;
+  offt_pass_desc d[3];
+  const void *src[3];
+  void *dst[3];
+  int slot[3]; /* which timer slot (0 = z, 1 = y, 2 = x) each launch feeds */
+  const int S = po->params->v[_S_] != 0;
+  const int zyx = !S && !(po->is_equalxy && c->M1 == c->M4);
 
-  /* z pass: contiguous lines */
-  desc_init(&dz, st, Nz, dir, 2);
-  dz.ncols = Ny; dz.nb1 = Nx;
-  dz.in_axis_stride = dz.out_axis_stride = 1;
-  dz.in_contig = dz.out_contig = 1;
-  /* y pass: axis stride = row length, columns along z */
-  desc_init(&dy, st, Ny, dir, 1);
-  dy.ncols = Nz; dy.nb1 = Nx;
-  dy.in_axis_stride = dy.out_axis_stride = ws1;
-  dy.in_col_stride = dy.out_col_stride = 1;
-  dy.in_b1_stride = dy.out_b1_stride = ws0;
-  /* x pass */
-  desc_init(&dx, st, Nx, dir, 0);
-
-  if (dir < 0) {
-    dz.in_col_stride = is1; dz.in_b1_stride = is0;
-    dz.out_col_stride = ws1; dz.out_b1_stride = ws0;
-    if (in_place) {
-      dx.ncols = (is0 == (long long)Ny * is1 && is1 == Nz) ? Ny * Nz : Nz;
-      dx.nb1 = dx.ncols == Nz ? Ny : 1;
-      dx.in_axis_stride = dx.out_axis_stride = ws0;
-      dx.in_col_stride = dx.out_col_stride = 1;
-      dx.in_b1_stride = dx.out_b1_stride = ws1;
+  if (S) {
+    /* x-y-z output == input layout: three in-place passes, strided along y and x */
+    desc_init(&d[0], st, Nz, dir, 2);
+    d[0].ncols = Ny; d[0].nb1 = Nx;
+    d[0].in_axis_stride = d[0].out_axis_stride = 1;
+    d[0].in_col_stride = d[0].out_col_stride = is1;
+    d[0].in_b1_stride = d[0].out_b1_stride = is0;
+    d[0].in_contig = d[0].out_contig = 1;
+    desc_init(&d[1], st, Ny, dir, 1);
+    d[1].ncols = Nz; d[1].nb1 = Nx;
+    d[1].in_axis_stride = d[1].out_axis_stride = is1;
+    d[1].in_col_stride = d[1].out_col_stride = 1;
+    d[1].in_b1_stride = d[1].out_b1_stride = is0;
+    desc_init(&d[2], st, Nx, dir, 0);
+    if (is0 == (long long)Ny * is1 && is1 == Nz) { d[2].ncols = Ny * Nz; d[2].nb1 = 1; }
+    else { d[2].ncols = Nz; d[2].nb1 = Ny; }
+    d[2].in_axis_stride = d[2].out_axis_stride = is0;
+    d[2].in_col_stride = d[2].out_col_stride = 1;
+    d[2].in_b1_stride = d[2].out_b1_stride = is1;
+    for (int i = 0; i < 3; i++) { src[i] = data; dst[i] = data; slot[i] = i; }
+  } else if (zyx) {
+    /* default z-y-x output.  Every pass READS whole contiguous lines and the
+     * axis rotation rides on the stores (128-B column segments, row pitch of
+     * one line), so no pass walks memory at a plane-sized stride:
+     *   P1  [x][y][z] --FFTz--> W[x][z][y]     (local transpose folded in)
+     *   P2  W[x][z][y] --FFTy--> out[z][y][x]  (columns = 8 x-planes)
+     *   P3  out[z][y][x] --FFTx--> in place
+     * this replaces FFTz + pack/unpack + setup_transpose's xzy->zxy permutation
+     * + FFTy + FFTx of the reference (offt-compute.c:625-634, 4019-4036). */
+    const long long wx = (long long)Nz * Ny; /* W plane */
+    desc_init(&d[0], st, Nz, dir, 2);
+    desc_init(&d[1], st, Ny, dir, 1);
+    desc_init(&d[2], st, Nx, dir, 0);
+    if (dir < 0) {
+      d[0].ncols = Ny; d[0].nb1 = Nx;
+      d[0].in_axis_stride = 1; d[0].in_col_stride = is1; d[0].in_b1_stride = is0; d[0].in_contig = 1;
+      d[0].out_axis_stride = Ny; d[0].out_col_stride = 1; d[0].out_b1_stride = wx; d[0].out_contig = 0;
+      d[1].ncols = Nx; d[1].nb1 = Nz;
+      d[1].in_axis_stride = 1; d[1].in_col_stride = wx; d[1].in_b1_stride = Ny; d[1].in_contig = 1;
+      d[1].out_axis_stride = os1; d[1].out_col_stride = os0; d[1].out_b1_stride = os2; d[1].out_contig = 0;
+      d[2].ncols = Ny; d[2].nb1 = Nz;
+      d[2].in_axis_stride = d[2].out_axis_stride = os0;
+      d[2].in_col_stride = d[2].out_col_stride = os1;
+      d[2].in_b1_stride = d[2].out_b1_stride = os2;
+      d[2].in_contig = d[2].out_contig = 1;
+      src[0] = data; dst[0] = W; src[1] = W; dst[1] = data; src[2] = data; dst[2] = data;
+      slot[0] = 0; slot[1] = 1; slot[2] = 2;
     } else {
-      dx.ncols = Nz; dx.nb1 = Ny;
-      dx.in_axis_stride = ws0; dx.in_col_stride = 1; dx.in_b1_stride = ws1;
-      dx.out_axis_stride = os0; dx.out_col_stride = os2; dx.out_b1_stride = os1;
-      dx.out_contig = (os0 == 1);
+      /* inverse: the same three steps backwards (x in place, y -> W, z -> input layout) */
+      offt_pass_desc t;
+      d[2].ncols = Ny; d[2].nb1 = Nz;
+      d[2].in_axis_stride = d[2].out_axis_stride = os0;
+      d[2].in_col_stride = d[2].out_col_stride = os1;
+      d[2].in_b1_stride = d[2].out_b1_stride = os2;
+      d[2].in_contig = d[2].out_contig = 1;
+      d[1].ncols = Nx; d[1].nb1 = Nz;
+      d[1].in_axis_stride = os1; d[1].in_col_stride = os0; d[1].in_b1_stride = os2; d[1].in_contig = 0;
+      d[1].out_axis_stride = 1; d[1].out_col_stride = wx; d[1].out_b1_stride = Ny; d[1].out_contig = 1;
+      d[0].ncols = Ny; d[0].nb1 = Nx;
+      d[0].in_axis_stride = Ny; d[0].in_col_stride = 1; d[0].in_b1_stride = wx; d[0].in_contig = 0;
+      d[0].out_axis_stride = 1; d[0].out_col_stride = is1; d[0].out_b1_stride = is0; d[0].out_contig = 1;
+      t = d[0]; d[0] = d[2]; d[2] = t; /* launch order x, y, z */
+      src[0] = data; dst[0] = data; src[1] = data; dst[1] = W; src[2] = W; dst[2] = data;
+      slot[0] = 2; slot[1] = 1; slot[2] = 0;
     }
-    dx.scale = st->out_scale;
-    be->event_record(st->evp[0], s);
-    if (be->pass(&dz, base, mid, s)) return -1;
-    be->event_record(st->evp[1], s);
-    if (be->pass(&dy, mid, mid, s)) return -1;
-    be->event_record(st->evp[2], s);
-    if (be->pass(&dx, mid, base, s)) return -1;
-    be->event_record(st->evp[3], s);
   } else {
-    /* inverse: output layout -> input layout, passes in reverse order */
-    if (in_place) {
-      dx.ncols = (is0 == (long long)Ny * is1 && is1 == Nz) ? Ny * Nz : Nz;
-      dx.nb1 = dx.ncols == Nz ? Ny : 1;
-      dx.in_axis_stride = dx.out_axis_stride = ws0;
-      dx.in_col_stride = dx.out_col_stride = 1;
-      dx.in_b1_stride = dx.out_b1_stride = ws1;
+    /* y-z-x output (is_equalxy): z and y passes in the natural layout inside W,
+     * the x pass transposes into the caller's layout */
+    const long long w1 = Nz, w0 = (long long)Ny * Nz;
+    desc_init(&d[0], st, Nz, dir, 2);
+    d[0].ncols = Ny; d[0].nb1 = Nx; d[0].in_axis_stride = d[0].out_axis_stride = 1;
+    d[0].in_contig = d[0].out_contig = 1;
+    desc_init(&d[1], st, Ny, dir, 1);
+    d[1].ncols = Nz; d[1].nb1 = Nx;
+    d[1].in_axis_stride = d[1].out_axis_stride = w1;
+    d[1].in_col_stride = d[1].out_col_stride = 1;
+    d[1].in_b1_stride = d[1].out_b1_stride = w0;
+    desc_init(&d[2], st, Nx, dir, 0);
+    d[2].ncols = Nz; d[2].nb1 = Ny;
+    if (dir < 0) {
+      d[0].in_col_stride = is1; d[0].in_b1_stride = is0; d[0].out_col_stride = w1; d[0].out_b1_stride = w0;
+      d[2].in_axis_stride = w0; d[2].in_col_stride = 1; d[2].in_b1_stride = w1;
+      d[2].out_axis_stride = os0; d[2].out_col_stride = os2; d[2].out_b1_stride = os1; d[2].out_contig = (os0 == 1);
+      src[0] = data; dst[0] = W; src[1] = W; dst[1] = W; src[2] = W; dst[2] = data;
+      slot[0] = 0; slot[1] = 1; slot[2] = 2;
     } else {
-      dx.ncols = Nz; dx.nb1 = Ny;
-      dx.in_axis_stride = os0; dx.in_col_stride = os2; dx.in_b1_stride = os1;
-      dx.in_contig = (os0 == 1);
-      dx.out_axis_stride = ws0; dx.out_col_stride = 1; dx.out_b1_stride = ws1;
+      offt_pass_desc t;
+      d[2].in_axis_stride = os0; d[2].in_col_stride = os2; d[2].in_b1_stride = os1; d[2].in_contig = (os0 == 1);
+      d[2].out_axis_stride = w0; d[2].out_col_stride = 1; d[2].out_b1_stride = w1;
+      d[0].in_col_stride = w1; d[0].in_b1_stride = w0; d[0].out_col_stride = is1; d[0].out_b1_stride = is0;
+      t = d[0]; d[0] = d[2]; d[2] = t;
+      src[0] = data; dst[0] = W; src[1] = W; dst[1] = W; src[2] = W; dst[2] = data;
+      slot[0] = 2; slot[1] = 1; slot[2] = 0;
     }
-    dz.in_col_stride = ws1; dz.in_b1_stride = ws0;
-    dz.out_col_stride = is1; dz.out_b1_stride = is0;
-    dz.scale = st->out_scale;
-    be->event_record(st->evp[0], s);
-    if (be->pass(&dx, base, mid, s)) return -1;
-    be->event_record(st->evp[1], s);
-    if (be->pass(&dy, mid, mid, s)) return -1;
-    be->event_record(st->evp[2], s);
-    if (be->pass(&dz, mid, base, s)) return -1;
-    be->event_record(st->evp[3], s);
   }
+  d[2].scale = st->out_scale; /* last launch */
+  for (int i = 0; i < 3; i++) st->pass_slot[i] = slot[i];
+  if (zyx && dir < 0 && st->zchunk > 0 && st->zchunk < Nz) {
+    /* Infinity-Cache blocking: run P2 and P3 back to back on slabs of `zchunk`
+     * z-planes, so that P3 finds the slab P2 just wrote still in the 256 MiB
+     * last-level cache instead of re-reading it from HBM. */
+    be->event_record(st->evp[0], s);
+    if (be->pass(&d[0], src[0], dst[0], s)) return -1;
+    be->event_record(st->evp[1], s);
+    for (int z0 = 0; z0 < Nz; z0 += st->zchunk) {
+      const int nz = (Nz - z0 < st->zchunk) ? Nz - z0 : st->zchunk;
+      offt_pass_desc a = d[1], b = d[2];
+      a.nb1 = nz; b.nb1 = nz;
+      const char *s1 = (const char *)src[1] + (size_t)z0 * d[1].in_b1_stride * st->esz;
+      char *o1 = (char *)dst[1] + (size_t)z0 * d[1].out_b1_stride * st->esz;
+      if (be->pass(&a, s1, o1, s)) return -1;
+      if (be->pass(&b, o1, o1, s)) return -1;
+    }
+    be->event_record(st->evp[2], s);
+    be->event_record(st->evp[3], s);
+    return 0;
+  }
+  for (int i = 0; i < 3; i++) {
+    be->event_record(st->evp[i], s);
+    if (be->pass(&d[i], src[i], dst[i], s)) return -1;
+  }
+  be->event_record(st->evp[3], s);
   return 0;
 }
 
@@ -851,12 +921,10 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     double ph1 = 1e-3 * be->event_ms(st->evp[0], st->evp[2]);
     st->pass_s[0] = ph1; st->pass_s[1] = 0; st->pass_s[2] = cc;
     t[PACK1] = ph1; t[FFTx] = cc;
-  } else if (direction < 0) {
-    st->pass_s[0] = a; st->pass_s[1] = b; st->pass_s[2] = cc;
-    t[FFTz] = a; t[FFTy1] = b; t[FFTx] = cc;
   } else {
-    st->pass_s[0] = cc; st->pass_s[1] = b; st->pass_s[2] = a;
-    t[FFTz] = cc; t[FFTy1] = b; t[FFTx] = a;
+    const double tt[3] = {a, b, cc};
+    for (int i = 0; i < 3; i++) st->pass_s[st->pass_slot[i]] = tt[i];
+    t[FFTz] = st->pass_s[0]; t[FFTy1] = st->pass_s[1]; t[FFTx] = st->pass_s[2];
   }
   if (staged) HCHECK(hipMemcpy(out, st->stage, bytes, hipMemcpyDeviceToHost), { t[ALL] = 99999999.0; return; });
   t[ALL] = wall_seconds() - t0;

@@ -140,7 +140,12 @@ struct PanelCfg {
   static constexpr int WG_PER_CU_LDS = LDS_BYTES ? (int)(160 * 1024 / LDS_BYTES) : 8;
   static constexpr int WPS_RAW = (WG_PER_CU_LDS * NT + 255) / 256;
   static constexpr int WPS = WPS_RAW < 1 ? 1 : (WPS_RAW > 4 ? 4 : WPS_RAW);
-  static constexpr int WPS_E = (E * (int)sizeof(T) >= 256 && WPS > 2) ? 2 : WPS;
+  // register budget: an E-point thread keeps E*sizeof(T)/2 data VGPRs; it needs
+  // roughly twice that (butterfly temporaries, addresses, exchange staging)
+  static constexpr int DATA_VGPR = E * (int)sizeof(T) / 2;
+  static constexpr int WPS_REG = DATA_VGPR >= 128 ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
+  static constexpr int WPS_MIN = (NT + 255) / 256;  // one workgroup must fit on a CU
+  static constexpr int WPS_E = WPS < WPS_REG ? WPS : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
 };
 
 template <int PADSHIFT>
@@ -432,6 +437,7 @@ struct Variant {
   int n, prec;
   bool inc, outc;
   int id;
+  bool is_default;  // default for this (n, prec, inc, outc) flavour
   int cols, threads;
   size_t lds;
   const void *fn;
@@ -444,26 +450,34 @@ std::vector<Variant> &registry() {
   return r;
 }
 
+// flavour bits for `defmask`: which (in_contig, out_contig) kernels use this variant by default
+enum { F_CC = 1, F_SS = 2, F_CS = 4, F_SC = 8, F_ALL = 15 };
+
 template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
-void reg_variant(int id) {
+void reg_variant(int id, int defmask = -1) {
+  if (defmask < 0) defmask = id == 0 ? F_ALL : 0;
   using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
   const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
   char nm[160];
   snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
            R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
-  auto add = [&](bool inc, bool outc, const void *fn) {
-    registry().push_back(Variant{N, prec, inc, outc, id, COLS, Cfg::NT, Cfg::LDS_BYTES, fn, nm, false});
+  auto add = [&](bool inc, bool outc, int bit, const void *fn) {
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, COLS, Cfg::NT, Cfg::LDS_BYTES, fn, nm, false});
   };
-  add(true, true, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
-  add(false, false, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
-  add(true, false, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
-  add(false, true, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
+  add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
+  add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
+  add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
+  add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
 }
 
 std::once_flag g_reg_once;
 void build_registry() {
   // variant 0 of every length is the default; higher ids are the static sweep
   // (LDS tile width x radix order x re/im split), see DESIGN.md section 5.
+#ifdef OFFT_DEV_ONLY_1024  /* developer switch: compile just the 1024 kernels for quick iteration */
+  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
+  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
+#else
   // ---- f64 ----
   reg_variant<double, 2, 2, 2, 1, 1, 64, false>(0);
   reg_variant<double, 4, 4, 4, 1, 1, 64, false>(0);
@@ -473,11 +487,14 @@ void build_registry() {
   reg_variant<double, 64, 8, 8, 8, 1, 8, false>(0);
   reg_variant<double, 128, 16, 16, 8, 1, 8, false>(0);
   reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0);
-  reg_variant<double, 512, 32, 32, 16, 1, 8, true>(0);
-  reg_variant<double, 512, 16, 16, 16, 2, 8, true>(1);
-  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1);
-  reg_variant<double, 1024, 32, 32, 32, 1, 4, false>(2);
+  reg_variant<double, 512, 32, 32, 16, 1, 8, true>(0, 0);
+  reg_variant<double, 512, 16, 16, 16, 2, 8, true>(1, F_ALL);
+  // static sweep result (profiles/r01_sweep.txt): E=16 (radix 16x16x4, 4 waves/SIMD, no
+  // spills) beats E=32 (radix 32x32, one exchange fewer but 256 VGPRs and 2 waves/SIMD)
+  // on every flavour at 1024^3, so it is the default; E=32 stays selectable as variant 0.
+  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
+  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
+  reg_variant<double, 1024, 32, 32, 32, 1, 4, false>(2, 0);
   reg_variant<double, 2048, 32, 32, 32, 2, 8, true>(0);
   reg_variant<double, 4096, 32, 32, 32, 4, 4, true>(0);
   // ---- f32 ----
@@ -493,6 +510,7 @@ void build_registry() {
   reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0);
   reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
   reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
+#endif
 }
 
 Variant *find_variant(int n, int prec, bool inc, bool outc, int id) {
@@ -501,7 +519,7 @@ Variant *find_variant(int n, int prec, bool inc, bool outc, int id) {
   for (auto &v : registry()) {
     if (v.n == n && v.prec == prec && v.inc == inc && v.outc == outc) {
       if (v.id == id) return &v;
-      if (v.id == 0) def = &v;
+      if (v.is_default) def = &v;
     }
   }
   return def;
@@ -571,7 +589,7 @@ int get_tables(int n, int prec, Tables &out, bool create) {
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 bool fast_ok(const offt_pass_desc *d) {
-  if (!find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, 0)) return false;
+  if (!find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1)) return false;
   if (d->in_split_nfloor > 0 || d->out_split_nfloor > 0) return false;
   if (d->in_split && !is_pow2(d->in_split)) return false;
   if (d->out_split && !is_pow2(d->out_split)) return false;
@@ -587,7 +605,7 @@ extern "C" {
 const char *offt_hipk_last_error(void) { return g_err; }
 
 int offt_hipk_has_fast_path(int n, int precision) {
-  return find_variant(n, precision, true, true, 0) != nullptr;
+  return find_variant(n, precision, true, true, -1) != nullptr;
 }
 
 int offt_hipk_variant_count(int n, int precision) {
@@ -624,7 +642,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
   if (fast_ok(d)) {
-    Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, d->variant < 0 ? 0 : d->variant);
+    Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, d->variant);
     PassArgs a;
     a.in_axis = d->in_axis_stride; a.in_col = d->in_col_stride; a.in_b1 = d->in_b1_stride; a.in_b2 = d->in_b2_stride;
     a.out_axis = d->out_axis_stride; a.out_col = d->out_col_stride; a.out_b1 = d->out_b1_stride; a.out_b2 = d->out_b2_stride;
@@ -663,6 +681,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   size_t lds = (size_t)d->n * esz;
   if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: n=%d too long for the generic kernel", d->n); return -1; }
   int threads = d->n >= 256 ? 256 : (d->n > 64 ? 128 : 64);
+  (void)hipGetLastError();  // start from a clean slate: the check below must see only this launch
   if (d->precision == OFFT_PREC_F64) {
     static bool set64 = false;
     if (lds > 48 * 1024 && !set64) {

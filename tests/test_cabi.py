@@ -45,6 +45,8 @@ def test_struct_mirror_sizes(built):
 def test_print_formats(built, capfd):
     """stdout formats the reference harness relies on (offt-compute.c:3239-3294)"""
     L = api.lib()
+    C.CDLL(None).fflush(None)  # drop whatever earlier tests left in the C stdio buffer
+    capfd.readouterr()
     v = (C.c_int * 24)(*range(24))
     v[3] = -1
     L.print_params(v)

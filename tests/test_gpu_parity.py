@@ -101,12 +101,15 @@ def test_forward_inverse_roundtrip_512(built, layout):
                           is_equalxy=eq)
     L = api.lib()
     dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()  # the plan runs on its own non-blocking stream: order it after torch's fill
     L.offt_hip_fill_input(po, dev.data_ptr(), 1)
     x0 = dev.clone()
+    torch.cuda.synchronize()
     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
     # Parseval on the forward result
     e_in, e_out = float((x0 * x0).sum()), float((dev * dev).sum())
     assert abs(e_out / n ** 3 - e_in) / e_in < 1e-13
+    torch.cuda.synchronize()
     api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
     dev /= n ** 3
     err = float(torch.linalg.vector_norm(dev - x0) / torch.linalg.vector_norm(x0))
@@ -121,6 +124,7 @@ def test_full_size_1024_properties(built):
     L = api.lib()
     c = api.comm_dict(po)
     dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
     L.offt_hip_fill_input(po, dev.data_ptr(), 0)  # harness ramp
     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
     cv = torch.view_as_complex(dev.view(-1, 2))
@@ -133,6 +137,7 @@ def test_full_size_1024_properties(built):
         assert abs(complex(cv[k * os0]) - 100 * cf) / abs(100 * cf) < 1e-12
     # everything off the three axes is zero for a separable ramp
     assert abs(complex(cv[os0 + os1 + os2])) / n ** 3 < 1e-9
+    torch.cuda.synchronize()
     L.offt_hip_fill_input(po, dev.data_ptr(), 1)
     e_in = float((dev * dev).sum())
     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
@@ -177,7 +182,7 @@ def test_host_pointer_boundary(built):
     n = 32
     po = api.offt_3d_init(n, n, n)
     f = O.hash_field(n, n, n)
-    buf = np.ascontiguousarray(f.ravel())
+    buf = f.ravel().copy()  # in-place transform: keep f intact for the check
     p = buf.ctypes.data_as(C.c_void_p)
     api.offt_3d_execute(po, p, p)
     c = api.comm_dict(po)

@@ -13,6 +13,7 @@ def run(N, S, eq, variants=(-1, -1, -1), prec=api.F64, reps=4):
         L.offt_hip_set_variant(po, ax, v)
     n = api.local_elems(po)
     dev = torch.zeros(n * 2, dtype=torch.float64 if prec == api.F64 else torch.float32, device="cuda")
+    torch.cuda.synchronize()
     L.offt_hip_fill_input(po, dev.data_ptr(), 1)
     best = None
     for r in range(reps):
@@ -33,6 +34,12 @@ def run(N, S, eq, variants=(-1, -1, -1), prec=api.F64, reps=4):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    if len(sys.argv) > 2 and sys.argv[2] == "zchunk":
+        for ch in (0, 1, 2, 4, 8, 16, 32):
+            os.environ["OFFT_ZCHUNK"] = str(ch)
+            print("OFFT_ZCHUNK", ch)
+            run(N, 0, 0)
+        sys.exit(0)
     for S, eq in ((1, 0), (0, 0), (0, 1)):
         run(N, S, eq)
     nv = api.lib().offt_hipk_variant_count(N, 0)

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Summarise build/kernel_resource_usage.txt (hipcc -Rpass-analysis=kernel-resource-usage)."""
+import re, sys
+txt = open(sys.argv[1] if len(sys.argv) > 1 else "build/kernel_resource_usage.txt").read()
+minN = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+for b in re.split(r"remark: Function Name: ", txt)[1:]:
+    name = b.split()[0]
+    m = re.search(r"fft_panel_kI(\w)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)", name)
+    if not m:
+        continue
+    t, N, E, r0, r1, r2, cols, inc, outc, split = m.groups()
+    if int(N) < minN:
+        continue
+    def g(k):
+        mm = re.search(k + r": (\d+)", b)
+        return mm.group(1) if mm else "?"
+    print(f"{t} N={N} E={E} {r0}x{r1}x{r2} cols={cols} inc={inc} outc={outc} split={split}: VGPR", g(" VGPRs"), "AGPR", g("AGPRs"),
+          "spill", g("VGPRs Spill"), "scratch", g(r"ScratchSize \[bytes/lane\]"), "occ", g(r"Occupancy \[waves/SIMD\]"))
