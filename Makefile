@@ -38,3 +38,15 @@ clean:
 # test-only CPU interpreter of pass descriptors (never linked into the product)
 tests/libcpubackend.so: tests/cpu_backend.c oracle/oracle_fft.c oracle/oracle.h offt_amd/csrc/offt_backend.h
 	$(CC) -std=gnu11 -O2 -fPIC -shared -Ioracle -Ioffamd -I$(CSRC) -o $@ tests/cpu_backend.c oracle/oracle_fft.c -lm
+
+# run-fft-compatible C harness.  MPI=1 builds the multi-rank variant
+# against an MPI found at MPI_PREFIX (e.g. /opt/conda).
+MPI_PREFIX ?= /opt/conda
+harness: bin/run-fft
+bin/run-fft: harness/run-fft.c offt_amd/liboffthip.so
+	mkdir -p bin
+ifeq ($(MPI),1)
+	$(CC) -std=gnu11 -O2 -Wall -DOFFT_HARNESS_MPI -Iinclude -I$(MPI_PREFIX)/include -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -L$(MPI_PREFIX)/lib -lmpi -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath,$(MPI_PREFIX)/lib
+else
+	$(CC) -std=gnu11 -O2 -Wall -Iinclude -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib
+endif

@@ -70,7 +70,8 @@ def main():
     torch.cuda.set_device(local_rank)
     L = api.lib()
     dist = None
-    if world > 1:
+    force_dist = bool(int(os.environ.get("OFFT_BENCH_FORCE_DIST", "0")))  # rehearse the multi-rank plumbing on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         uid = torch.zeros(128, dtype=torch.uint8)
@@ -88,7 +89,7 @@ def main():
     n = args.n
     E = float(n) ** 3
     params = {}
-    if world > 1:
+    if world > 1 or force_dist:
         params["P1"] = args.p1 if args.p1 > 0 else 1
     if args.layout == "xyz":
         params["S"] = 1

@@ -1,0 +1,180 @@
+/*
+ * run-fft.c -- benchmark / smoke harness for the MI355X OFFT library.
+ *
+ * Counterpart of the reference's run-fft.c for its own algorithm (-a 0): the same
+ * command-line letters (run-fft.c:171-231), the same stdout lines ("@ INPUT", "@ FINAL",
+ * "t_init", "t_<r>", "t_fin", "t_all", "t_min", "p <rank>: x y z: re im",
+ * run-fft.c:235-251, 321, 358-367, 400-407, 438-449, 501) so that existing job scripts
+ * (job-test.sh:9-13) and log parsers keep working.  Differences, all additive:
+ *   -D        keep the grid in a host calloc()ed array like the reference (staged
+ *             through HBM on every execute); default is device-resident data filled
+ *             by a kernel
+ *   -g        print GFLOP/s (5 E log2 E) and the achieved fraction of the HBM roofline
+ *   comparison back-ends (-a 1/2/3: FFTW-MPI, P3DFFT, 2DECOMP) are not part of the path.
+ * World: one process per GPU.  Built with -DOFFT_HARNESS_MPI it takes rank/size from
+ * MPI and broadcasts the RCCL unique id with MPI_Bcast; without, it is a single rank.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#ifdef OFFT_HARNESS_MPI
+#include <mpi.h>
+#endif
+#include "offt_hip.h"
+
+static double now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void host_ramp(double *in, const struct _offt_comm *c) { /* run-fft.c:46-61 */
+  for (int x = 0; x < c->isize[0]; x++)
+    for (int y = 0; y < c->isize[1]; y++)
+      for (int z = 0; z < c->isize[2]; z++) {
+        size_t o = 2 * ((size_t)z + (size_t)c->istride[1] * y + (size_t)c->istride[0] * x);
+        in[o] = z + 10 * (y + c->istart[1]) + 100 * (x + c->istart[0]);
+        in[o + 1] = 0.0;
+      }
+}
+
+int main(int argc, char **argv) {
+  int Nx = 32, Ny = 32, Nz = 32, p1 = -1, reps = 1, p = 1, rank = 0;
+  int fftw_level = 0, ah_strategy = 0, max_loop = 0, tuning_mode = 0, is_W0 = 0, extrapolation_window = 0;
+  int is_oned = 0, is_a2a = 0, is_equalxy = 0, is_notest = 0, fft_alg = 0, verbose = 0, is_r2c = 0;
+  int host_data = 0, gflops = 0;
+  unsigned fftw_flag = FFTW_ESTIMATE;
+#ifdef OFFT_HARNESS_MPI
+  MPI_Init(&argc, &argv);
+  MPI_Comm_size(MPI_COMM_WORLD, &p);
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  {
+    char id[OFFT_HIP_UNIQUE_ID_BYTES];
+    memset(id, 0, sizeof id);
+    if (rank == 0 && p > 1 && offt_hip_get_unique_id(id)) MPI_Abort(MPI_COMM_WORLD, 2);
+    MPI_Bcast(id, sizeof id, MPI_BYTE, 0, MPI_COMM_WORLD);
+    const char *lr = getenv("OFFT_LOCAL_RANK");
+    int dev = lr ? atoi(lr) : rank % (getenv("OFFT_GPUS_PER_NODE") ? atoi(getenv("OFFT_GPUS_PER_NODE")) : 8);
+    if (offt_hip_set_world(rank, p, p > 1 ? id : NULL, dev)) MPI_Abort(MPI_COMM_WORLD, 3);
+  }
+#endif
+  struct _offt_params *cp = (struct _offt_params *)malloc(sizeof *cp);
+  for (int i = 0; i < PARAM_COUNT; i++) cp->v[i] = -1;
+  static const struct { char opt; int idx; } pmap[] = {
+      {'T', _T1_}, {'W', _W1_}, {'t', _T2_}, {'w', _W2_}, {'Y', _Ry_}, {'P', _Px1_}, {'p', _Py1_}, {'X', _Px2_},
+      {'Z', _Pz2_}, {'U', _Ux1_}, {'u', _Uz1_}, {'y', _Uy2_}, {'z', _Uz2_}, {'E', _Fz_}, {'F', _Fy1_}, {'f', _Fy2_},
+      {'G', _Fx_}, {'H', _FP1_}, {'h', _FP2_}, {'I', _FU1_}, {'i', _FU2_}, {'V', _V_}, {'S', _S_}};
+  int c;
+  while ((c = getopt(argc, argv, "N:n:L:va:Rr:m:A:O:Qobecs:l:d:T:W:t:w:P:p:X:Y:Z:U:u:y:z:E:F:f:G:H:h:I:i:V:S:Dg")) >= 0) {
+    switch (c) {
+      case 'N': Nx = atoi(optarg); break;
+      case 'n': Ny = atoi(optarg); break;
+      case 'L': Nz = atoi(optarg); break;
+      case 'v': verbose = 1; break;
+      case 'a': fft_alg = atoi(optarg); break;
+      case 'R': is_r2c = 1; break;
+      case 'r': reps = atoi(optarg); break;
+      case 'm': {
+        static const unsigned lv[4] = {FFTW_ESTIMATE, FFTW_MEASURE, FFTW_PATIENT, FFTW_EXHAUSTIVE};
+        fftw_level = atoi(optarg); fftw_flag = lv[fftw_level % 4];
+      } break;
+      case 'o': is_oned = 1; break;
+      case 'b': is_a2a = 1; break;
+      case 'e': is_equalxy = 1; break;
+      case 'c': is_notest = 1; break;
+      case 's': ah_strategy = atoi(optarg); break;
+      case 'l': max_loop = atoi(optarg); break;
+      case 'O': tuning_mode = atoi(optarg); break;
+      case 'Q': is_W0 = 1; break;
+      case 'A': extrapolation_window = atoi(optarg); break;
+      case 'd': p1 = cp->v[_P1_] = atoi(optarg); break;
+      case 'D': host_data = 1; break;
+      case 'g': gflops = 1; break;
+      default:
+        for (size_t k = 0; k < sizeof pmap / sizeof pmap[0]; k++)
+          if (pmap[k].opt == c) cp->v[pmap[k].idx] = atoi(optarg);
+    }
+  }
+  if (!rank) {
+    for (int a = 0; a < argc; a++) printf("%s ", argv[a]);
+    printf("\nNx %d Ny %d Nz %d p %d p1 %d r %d a %d m %d o %d b %d e %d c %d s %d l %d O %d Q %d A %d\n", Nx, Ny, Nz, p, p1,
+           reps, fft_alg, fftw_level, is_oned, is_a2a, is_equalxy, is_notest, ah_strategy, max_loop, tuning_mode, is_W0,
+           extrapolation_window);
+    printf("@ INPUT "); print_params(cp->v);
+  }
+  if (fft_alg != 0) {
+    if (!rank) printf("only -a 0 (OFFT) is part of this library; FFTW-MPI / P3DFFT / 2DECOMP back-ends are not built\nt_min 999999999.00000\n");
+    goto finish;
+  }
+  if (p1 == -1 && max_loop == 0) { /* run-fft.c:290-293 */
+    p1 = cp->v[_P1_] = p;
+    if (!rank) printf("set p1 = %d\n", p1);
+  }
+  double t = -now();
+  struct _offt_plan *po = offt_3d_init(Nx, Ny, Nz, NULL, NULL, is_r2c, (int)fftw_flag, is_oned, is_a2a, is_equalxy, is_notest,
+                                       ah_strategy, max_loop, tuning_mode, is_W0, extrapolation_window, cp);
+  if (!po) { fprintf(stderr, "offt_3d_init failed: %s\n", offt_hip_last_error()); goto finish; }
+  p1 = po->params->v[_P1_];
+  long long bytes = offt_hip_local_bytes(po);
+  if (!rank) printf("allocate memory for total # elements %lld\n", bytes / 16);
+  double *out = host_data ? (double *)calloc((size_t)bytes, 1) : (double *)offt_hip_malloc(bytes);
+  if (!out) { fprintf(stderr, "allocation of %lld bytes failed\n", bytes); goto finish; }
+  if (!rank) { printf("@ FINAL "); print_params(po->params->v); }
+  t += now();
+  if (!rank) printf("t_init %.5f %.5f %.5f %.5f\n", po->t_init[INIT_ALL], po->t_init[INIT_FFTW], po->t_init[INIT_AH], po->t_init[INIT_BUFFER]);
+
+  double t_min = 999999999.0, t_min_arr[GES];
+  memset(t_min_arr, 0, sizeof t_min_arr);
+  for (int r = 0; r < reps; r++) {
+    if (host_data) host_ramp(out, po->comm); else offt_hip_fill_input(po, out, 0);
+#ifdef OFFT_HARNESS_MPI
+    MPI_Barrier(MPI_COMM_WORLD);
+#endif
+    double t0 = now();
+    offt_3d_execute(po, out, out, 0);
+    double tc = now() - t0;
+    t += tc;
+    if (!rank) { printf("t_%d ", r); po->t[ALL] = tc; offt_print_time(po->t); }
+    if (tc < t_min) { t_min = tc; memcpy(t_min_arr, po->t, sizeof t_min_arr); }
+  }
+  double spot[4][2];
+  int nspot = 0;
+  if (verbose && rank == 0) { /* run-fft.c:452-503: out[x=0, y=0, z=0..3] through ostride */
+    int MM3 = Nz / (p / p1), zEnd = 4 > MM3 ? MM3 : 4;
+    for (int z = 0; z < zEnd; z++) {
+      size_t o = 2 * (size_t)z * po->comm->ostride[2];
+      if (host_data) { spot[z][0] = out[o]; spot[z][1] = out[o + 1]; }
+      else offt_hip_memcpy_d2h(spot[z], (char *)out + o * 8, 16);
+      nspot++;
+    }
+  }
+  double tf = -now();
+  int MM3p = Nz / (p / p1), MM4p = Ny / p1;
+  offt_3d_fin(po);
+  tf += now();
+  t += tf;
+  if (!rank) {
+    printf("t_fin %.5f\nt_all %.5f\nt_min ", tf, t);
+    offt_print_time(t_min_arr);
+    if (gflops) {
+      double E = (double)Nx * Ny * Nz, fl = 5.0 * E * log2(E), dev = t_min_arr[FFTz] + t_min_arr[FFTy1] + t_min_arr[FFTx] + t_min_arr[PACK1];
+      printf("gflops_wall %.1f gflops_device %.1f hbm_roofline_frac %.4f (6*16*E/p bytes, 8 TB/s)\n", fl / t_min / 1e9,
+             dev > 0 ? fl / dev / 1e9 : 0.0, dev > 0 ? 6.0 * 16.0 * E / p / dev / 8e12 : 0.0);
+    }
+    if (verbose) {
+      printf("p1 %d p2 %d MM3 %d MM4 %d\n", p1, p / p1, MM3p, MM4p);
+      for (int z = 0; z < nspot; z++) printf("p %d: %d %d %d: %.5f %.5f\n", rank, 0, 0, z, spot[z][0], spot[z][1]);
+    }
+  }
+  if (host_data) free(out); else offt_hip_free(out);
+finish:
+  free(cp);
+#ifdef OFFT_HARNESS_MPI
+  offt_hip_finalize_world();
+  MPI_Finalize();
+#endif
+  return 0;
+}

@@ -142,8 +142,8 @@ int offt_hip_set_world(int rank, int size, const void *id128, int device) {
   if (size < 1 || rank < 0 || rank >= size) { SET_ERR("bad world rank %d size %d", rank, size); return -1; }
   HCHECK(hipSetDevice(device), return -1);
   G.rank = rank; G.size = size; G.device = device; G.have_comm = 0;
-  if (size > 1) {
-    if (!id128) { SET_ERR("offt_hip_set_world: size %d needs an RCCL unique id", size); return -1; }
+  if (size > 1 && !id128) { SET_ERR("offt_hip_set_world: size %d needs an RCCL unique id", size); return -1; }
+  if (id128) { /* size 1 with an id: a one-rank communicator, used by the RCCL self-test */
     if (rccl_load()) return -1;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
@@ -314,6 +314,7 @@ typedef struct hip_state {
   void *work; size_t work_elems; /* single path: transposed-output scratch */
   /* pipeline */
   int T, ntiles, ring;
+  int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   void **send1, **recv1; /* ring */
   void **ev_k1, **ev_a1, **ev_k2;
@@ -324,6 +325,7 @@ typedef struct hip_state {
   int variant[3];
   double out_scale;
   int zchunk;
+  int wpad;
   int async;
   double last_dev_s, pass_s[3];
   int pass_slot[3];
@@ -494,6 +496,9 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->be = g_backend ? g_backend : &k_hip_backend;
   st->variant[0] = st->variant[1] = st->variant[2] = -1;
   st->out_scale = 1.0;
+  /* scratch planes are offset by an odd number of 128-B lines so that the 8 x-planes a
+   * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt) */
+  st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : 72;
   st->zchunk = getenv("OFFT_ZCHUNK") ? atoi(getenv("OFFT_ZCHUNK")) : 0;
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
@@ -516,12 +521,15 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
 
   if (!st->use_pipeline) {
     if (!po->params->v[_S_]) { /* transposed output layouts need one scratch volume */
-      st->work_elems = (size_t)Nx * Ny * Nz;
+      st->work_elems = (size_t)Nx * ((size_t)Ny * Nz + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
     }
   } else {
     int p1 = c->p1, p2 = c->p2;
+    const int force = getenv("OFFT_FORCE_A2A") && atoi(getenv("OFFT_FORCE_A2A"));
+    st->x1 = (p2 > 1) || force;
+    st->x2 = (p1 > 1) || force;
     st->T = po->params->v[_T1_];
     if (st->T > c->M1) st->T = c->M1;
     st->ntiles = (c->M1 + st->T - 1) / st->T;
@@ -532,29 +540,29 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     st->blk1 = (size_t)st->T * c->M2 * c->M3;
     st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
     st->send1 = (void **)calloc(st->ring, sizeof(void *));
-    st->recv1 = p2 > 1 ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
+    st->recv1 = st->x1 ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
     st->ev_k1 = (void **)calloc(st->ring, sizeof(void *));
     st->ev_a1 = (void **)calloc(st->ring, sizeof(void *));
     st->ev_k2 = (void **)calloc(st->ring, sizeof(void *));
     for (int r = 0; r < st->ring; r++) {
       st->send1[r] = be->dmalloc(st->blk1 * p2 * st->esz);
-      if (p2 > 1) st->recv1[r] = be->dmalloc(st->blk1 * p2 * st->esz);
+      if (st->x1) st->recv1[r] = be->dmalloc(st->blk1 * p2 * st->esz);
       st->ev_k1[r] = be->event_create(); st->ev_a1[r] = be->event_create(); st->ev_k2[r] = be->event_create();
       if (!st->send1[r] || !st->recv1[r]) goto fail;
     }
     st->recv2 = be->dmalloc(st->blk2 * p1 * st->esz);
-    st->send2 = p1 > 1 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
+    st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
     if (!st->recv2 || !st->send2) goto fail;
     st->ev_a2_last = be->event_create(); st->ev_k3 = be->event_create();
     st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create();
-    if (!g_backend && po->p > 1) {
+    if (!g_backend && (po->p > 1 || force)) {
       /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
        * (stride p2) -- offt-compute.c:78-125 */
       if (!G.have_comm) { SET_ERR("offt_3d_init: world of %d ranks but no RCCL communicator (offt_hip_set_world)", po->p); goto fail; }
       int rx = po->rank / p2, ry = po->rank % p2;
-      if (p2 > 1) { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), goto fail); st->have_comm1 = 1; }
+      if (st->x1) { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), goto fail); st->have_comm1 = 1; }
       else        { ncclComm_t tmp; NCHECK(R.CommSplit(G.world, -1, 0, &tmp, NULL), goto fail); }
-      if (p1 > 1) { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), goto fail); st->have_comm2 = 1; }
+      if (st->x2) { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), goto fail); st->have_comm2 = 1; }
       else        { ncclComm_t tmp; NCHECK(R.CommSplit(G.world, -1, 0, &tmp, NULL), goto fail); }
     }
   }
@@ -652,7 +660,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
      *   P3  out[z][y][x] --FFTx--> in place
      * this replaces FFTz + pack/unpack + setup_transpose's xzy->zxy permutation
      * + FFTy + FFTx of the reference (offt-compute.c:625-634, 4019-4036). */
-    const long long wx = (long long)Nz * Ny; /* W plane */
+    const long long wx = (long long)Nz * Ny + st->wpad; /* W plane (+ optional pad, elements) */
     desc_init(&d[0], st, Nz, dir, 2);
     desc_init(&d[1], st, Ny, dir, 1);
     desc_init(&d[2], st, Nx, dir, 0);
@@ -803,7 +811,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       }
       be->event_record(st->ev_k1[r], s);
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
-      if (p2 > 1) {
+      if (st->x1) {
         be->stream_wait(st->s_comm1, st->ev_k1[r]);
         const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2];
         for (int a = 0; a < p2; a++) {
@@ -820,7 +828,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- K2(k): unpack1 + FFTy (+ pack2) (offt-compute.c:1208-1520, 1636-2345) ---- */
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
-      if (p2 > 1) be->stream_wait(s, st->ev_a1[r]);
+      if (st->x1) be->stream_wait(s, st->ev_a1[r]);
       if (myT > 0 && c->m3 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Ny, dir, 1);
@@ -839,7 +847,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       }
       be->event_record(st->ev_k2[r], s);
       /* ---- a2a2(k) over comm2: x-tile k of every column block ---- */
-      if (p1 > 1) {
+      if (st->x2) {
         be->stream_wait(st->s_comm2, st->ev_k2[r]);
         const void *sp[p1]; void *rp[p1]; size_t sb[p1], rb[p1];
         int any = 0;
@@ -855,7 +863,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       }
     }
   }
-  if (p1 > 1) {
+  if (st->x2) {
     be->event_record(st->ev_a2_last, st->s_comm2);
     be->stream_wait(s, st->ev_a2_last);
   }

@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "offt_hipk.h"
 #include "offt_w32_consts.h"
 
@@ -123,11 +124,21 @@ struct PanelCfg {
   static constexpr int TPL = N / E;
   static constexpr int NT = TPL * COLS;
   static constexpr int NSTAGE = (R2 > 1) ? 3 : ((R1 > 1) ? 2 : 1);
+  // LDS image of one column: Stockham stage s writes index (q-k)*R + k + t*Ns with lanes
+  // along q and reads index q' + t'*(N/R') with lanes along q'.  Stage 0 (Ns = 1) is a
+  // stride-R0 write: all lanes of a ds_write group would hit one bank.
+  //  * R0 >= 16: XOR swizzle  i -> i ^ ((i >> log2 R0) & 15).  The strided writes spread
+  //    over 16 bank pairs, and the unit-stride accesses are only permuted inside aligned
+  //    16-element runs, so they stay conflict-free (a padded image misaligns them: the
+  //    PMC pass showed SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE with padding).
+  //  * R0 < 16 (small N): pad one element every R0.
+  static constexpr bool SWZ = (R0 >= 16);
   static constexpr int PADSHIFT = ilog2(R0) < 3 ? 3 : ilog2(R0);
-  static constexpr int NPAD = N + (N >> PADSHIFT);
-  // column stride: == 2 (mod 16) elements so that 8 columns x 2 rows of one
-  // 16-lane ds_write_b64 group land in 16 distinct bank pairs.
-  static constexpr int LSTRIDE = ((NPAD + 13) / 16) * 16 + 2;
+  static constexpr int SWZSHIFT = ilog2(R0);
+  static constexpr int NPAD = SWZ ? N : N + (N >> PADSHIFT);
+  // column pitch == 4 (mod 32) elements: the 8 columns x 4 rows of one 32-lane ds_read_b64
+  // group of a strided-store flavour land in 32 distinct bank pairs
+  static constexpr int LSTRIDE = SWZ ? ((NPAD + 31) / 32) * 32 + 4 : ((NPAD + 13) / 16) * 16 + 2;
   static constexpr int QT = (N >= 4) ? N / 4 + 1 : 1;
   static constexpr size_t EX_BYTES =
       NSTAGE > 1 ? (size_t)COLS * LSTRIDE * sizeof(T) * (SPLIT ? 1 : 2) : 0;
@@ -148,8 +159,11 @@ struct PanelCfg {
   static constexpr int WPS_E = WPS < WPS_REG ? WPS : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
 };
 
-template <int PADSHIFT>
-__device__ __forceinline__ int padidx(int i) { return i + (i >> PADSHIFT); }
+template <bool SWZ, int SHIFT>
+__device__ __forceinline__ int padidx(int i) {
+  if constexpr (SWZ) return i ^ ((i >> SHIFT) & 15);
+  else return i + (i >> SHIFT);
+}
 
 template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT>
 __global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
@@ -158,7 +172,9 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   using V2 = typename vec2<T>::type;
   using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
   constexpr int TPL = Cfg::TPL, NT = Cfg::NT, NSTAGE = Cfg::NSTAGE;
-  constexpr int LSTRIDE = Cfg::LSTRIDE, PS = Cfg::PADSHIFT;
+  constexpr int LSTRIDE = Cfg::LSTRIDE;
+  constexpr bool SWZ = Cfg::SWZ;
+  constexpr int PS = SWZ ? Cfg::SWZSHIFT : Cfg::PADSHIFT;
   static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
   static_assert(E % R0 == 0 && E % R1 == 0 && E % R2 == 0 && N % E == 0, "bad E");
 
@@ -245,10 +261,10 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       auto wr_idx = [&](int u, int t) {
         const int q = j + u * TPL;
         const int k = q & (Ns - 1);
-        return c * LSTRIDE + padidx<PS>((q - k) * R + k + t * Ns);
+        return c * LSTRIDE + padidx<SWZ, PS>((q - k) * R + k + t * Ns);
       };
       auto rd_idx = [&](int u, int t) {
-        return cn * LSTRIDE + padidx<PS>(jn + u * TPL + t * (N / Rn));
+        return cn * LSTRIDE + padidx<SWZ, PS>(jn + u * TPL + t * (N / Rn));
       };
 
       // (the twiddle table written at kernel entry becomes visible at the first
@@ -307,6 +323,50 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       });
     }
   });
+}
+
+// ---------------------------------------------------------------------------
+// Developer probe: the same panel addressing as fft_panel_k with the butterflies
+// and the LDS exchange removed (results are NOT a transform).  It measures the
+// HBM ceiling of a pass's access pattern; enabled with OFFT_COPY_ONLY=1 and used
+// only by tools/dev_perf.py.
+// ---------------------------------------------------------------------------
+template <typename T, int N, int E, int COLS, bool INC, bool OUTC>
+__global__ void __launch_bounds__((N / E) * COLS)
+panel_copy_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out) {
+  using V2 = typename vec2<T>::type;
+  constexpr int TPL = N / E;
+  const int tid = threadIdx.x;
+  const unsigned bid = blockIdx.x;
+  const int cp = bid % (unsigned)a.ncp;
+  const unsigned rest = bid / (unsigned)a.ncp;
+  const int b1 = rest % (unsigned)a.nb1;
+  const int b2 = rest / (unsigned)a.nb1;
+  const int c0 = cp * COLS;
+  V2 v[E];
+  int c, j;
+  if constexpr (INC) { j = tid % TPL; c = tid / TPL; } else { c = tid % COLS; j = tid / COLS; }
+  {
+    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
+    const int mask = (int)((1u << a.in_shift) - 1u);
+    static_for<0, E>([&](auto ii) {
+      const int n = j + decltype(ii)::value * TPL;
+      v[decltype(ii)::value] = src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis];
+    });
+  }
+  if constexpr (INC != OUTC) {
+    // a transposing pass changes which thread owns which element; emulate the exchange's
+    // barrier cost-free by simply re-mapping (data values are meaningless here)
+    if constexpr (OUTC) { j = tid % TPL; c = tid / TPL; } else { c = tid % COLS; j = tid / COLS; }
+  }
+  {
+    V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
+    const int mask = (int)((1u << a.out_shift) - 1u);
+    static_for<0, E>([&](auto ii) {
+      const int n = j + decltype(ii)::value * TPL;
+      dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis] = v[decltype(ii)::value];
+    });
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -660,6 +720,18 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
       if (v->lds > 48 * 1024)
         HIPK_CHECK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
       v->attr_set = true;
+    }
+    static const int copy_only = getenv("OFFT_COPY_ONLY") ? atoi(getenv("OFFT_COPY_ONLY")) : 0;
+    if (copy_only && d->n == 1024 && d->precision == OFFT_PREC_F64) {
+      a.ncp = (d->ncols + 7) / 8;
+      nblk = (long long)a.ncp * d->nb1 * d->nb2;
+      const void *fn = d->in_contig ? (d->out_contig ? (const void *)panel_copy_k<double, 1024, 16, 8, true, true>
+                                                     : (const void *)panel_copy_k<double, 1024, 16, 8, true, false>)
+                                    : (d->out_contig ? (const void *)panel_copy_k<double, 1024, 16, 8, false, true>
+                                                     : (const void *)panel_copy_k<double, 1024, 16, 8, false, false>);
+      void *cargs[] = {(void *)&a, (void *)&in, (void *)&out};
+      HIPK_CHECK(hipLaunchKernel(fn, dim3((unsigned)nblk), dim3(512), cargs, 0, st));
+      return 0;
     }
     void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tb.quarter};
     HIPK_CHECK(hipLaunchKernel(v->fn, dim3((unsigned)nblk), dim3(v->threads), args, v->lds, st));

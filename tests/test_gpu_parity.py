@@ -208,3 +208,21 @@ def test_sweep_variants_agree(built):
         got = read_output(po, dev, shape)
         api.offt_3d_fin(po)
         assert rel(got, base) < 1e-15 * 10
+
+
+def test_rccl_self_exchange_one_rank(built, monkeypatch):
+    """RCCL binding, communicator split, grouped send/recv and the stream/event ring, exercised with a
+    one-rank communicator (all the 1-GPU box allows): every tile goes through ncclSend/ncclRecv to self."""
+    L = api.lib()
+    uid = (C.c_char * 128)()
+    assert L.offt_hip_get_unique_id(uid) == 0, L.offt_hip_last_error()
+    assert L.offt_hip_set_world(0, 1, uid, 0) == 0, L.offt_hip_last_error()
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    monkeypatch.setenv("OFFT_FORCE_A2A", "1")
+    try:
+        for shape, kw in [((64, 64, 64), dict(T1=8, W1=2)), ((128, 64, 32), dict(T1=16, W1=1, S=1)), ((20, 12, 18), dict(T1=3, W1=0))]:
+            got, _ = gpu_fft(shape, **kw)
+            want, _, _ = O.world_fft(*shape, 1, kind=1, **kw)
+            check64(got, want)
+    finally:
+        L.offt_hip_finalize_world()

@@ -61,6 +61,17 @@ def test_single_rank_forced_pipeline(cpu1, monkeypatch):
         assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, (shape, kw)
 
 
+def test_forced_self_exchange(cpu1, monkeypatch):
+    """p = 1 with the exchanges forced on: separate send/receive buffers and the a2a callback in the loop"""
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    monkeypatch.setenv("OFFT_FORCE_A2A", "1")
+    for shape, kw in [((8, 8, 8), dict(T1=2, W1=1)), ((6, 10, 4), dict(T1=4, W1=2, S=1))]:
+        c, v, buf = cpu_world.run_rank(*shape, **kw)
+        G = np.zeros(shape, dtype=np.complex128)
+        cpu_world.scatter_out(c, buf, G)
+        assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, (shape, kw)
+
+
 def test_inverse_roundtrip_single(cpu1):
     for shape, kw in [((8, 4, 16), dict(S=1)), ((8, 8, 6), dict())]:
         cp = api.make_params(**kw)

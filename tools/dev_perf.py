@@ -34,6 +34,18 @@ def run(N, S, eq, variants=(-1, -1, -1), prec=api.F64, reps=4):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    if len(sys.argv) > 2 and sys.argv[2] == "copy":
+        os.environ["OFFT_COPY_ONLY"] = "1"
+        print("COPY ONLY (pattern ceiling, not a transform)")
+        for S, eq in ((1, 0), (0, 0), (0, 1)):
+            run(N, S, eq)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "wpad":
+        for pad in (0, 8, 64, 72, 520, 1032, 4104):
+            os.environ["OFFT_WPAD"] = str(pad)
+            print("OFFT_WPAD", pad)
+            run(N, 0, 0)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "zchunk":
         for ch in (0, 1, 2, 4, 8, 16, 32):
             os.environ["OFFT_ZCHUNK"] = str(ch)
