@@ -11,7 +11,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboffthip.so")
+LIB_PATH = os.environ.get("OFFT_AMD_LIB") or os.path.join(_HERE, "liboffthip.so")  # override: developer A/B builds
 _lib = None
 
 

@@ -309,11 +309,12 @@ typedef struct hip_state {
   int use_pipeline;     /* 0: single-rank direct 3-pass path, 1: tile pipeline */
   const offt_backend *be;
   void *s_compute; int own_stream;
-  void *s_comm1, *s_comm2;
+  void *s_comm1, *s_comm2, *s_k1;
   void *ev0, *ev1, *evp[4];
   void *work; size_t work_elems; /* single path: transposed-output scratch */
   /* pipeline */
   int T, ntiles, ring;
+  int slab_zyx;          /* p1 == 1 and z-y-x output: x-contiguous exchange layout, see execute_pipeline */
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   void **send1, **recv1; /* ring */
@@ -447,7 +448,7 @@ static void state_free(hip_state *st) {
   for (int i = 0; i < 4; i++) be->event_destroy(st->evp[i]);
   be->event_destroy(st->ev_a2_last); be->event_destroy(st->ev_k3);
   if (st->own_stream) be->stream_destroy(st->s_compute);
-  be->stream_destroy(st->s_comm1); be->stream_destroy(st->s_comm2);
+  be->stream_destroy(st->s_comm1); be->stream_destroy(st->s_comm2); be->stream_destroy(st->s_k1);
   if (st->have_comm1) R.CommDestroy(st->comm1);
   if (st->have_comm2) R.CommDestroy(st->comm2);
   free(st);
@@ -532,6 +533,9 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     st->x2 = (p1 > 1) || force;
     st->T = po->params->v[_T1_];
     if (st->T > c->M1) st->T = c->M1;
+    st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
+                   !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
+    if (st->slab_zyx) st->x2 = 0; /* p1 == 1: there is no second exchange, K2 stores K3's input directly */
     st->ntiles = (c->M1 + st->T - 1) / st->T;
     int W = po->params->v[_W1_];
     if (W < 0) W = 0;
@@ -554,7 +558,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
     if (!st->recv2 || !st->send2) goto fail;
     st->ev_a2_last = be->event_create(); st->ev_k3 = be->event_create();
-    st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create();
+    st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create(); st->s_k1 = be->stream_create();
     if (!g_backend && (po->p > 1 || force)) {
       /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
        * (stride p2) -- offt-compute.c:78-125 */
@@ -788,28 +792,43 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   for (int a = 0; a < p2; a++) peers1[a] = a; /* key = rank_y inside comm1 */
   for (int a = 0; a < p1; a++) peers2[a] = a; /* key = rank_x inside comm2 */
 
+  /* One in-order compute stream carries the reference's software pipeline
+   * "pack(i); wait(i-W); ia2a(i); unpack(i-W)" (offt-compute.c:3537-3647): K1(i) then
+   * K2(i-W), so that tile i's exchange runs under K1(i+1..i+W).  (Putting K1 and K2 on
+   * two streams was measured and is slower: cross-stream event edges cost more than the
+   * tail waves they fill -- profiles/r01_sweep.txt.) */
+  void *sA = s;
   be->event_record(st->evp[0], s);
   for (int i = 0; i < st->ntiles + W; i++) {
     if (i < st->ntiles) {
       /* ---- K1(i): FFTz + pack1 (offt-compute.c:905-1206) ---- */
       const int r = i % st->ring, x0 = i * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
-      if (i >= st->ring) be->stream_wait(s, st->ev_k2[r]); /* slot's previous tile fully consumed */
+      if (i >= st->ring) be->stream_wait(sA, st->ev_k2[r]); /* slot's previous tile fully consumed */
       if (myT > 0 && c->m2 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Nz, dir, 2);
         d.ncols = c->m2; d.nb1 = myT;
         d.in_axis_stride = 1; d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.in_contig = 1;
-        d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
+        if (st->slab_zyx) {
+          /* panel = 8 x-lines at one y; per-peer block [z_l][y][x_t]: x fastest, so that the
+           * y pass can emit x-contiguous segments and the x pass reads whole lines */
+          d.ncols = myT; d.nb1 = c->m2;
+          d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1];
+          d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
+          d.out_contig = 0;
+        } else {
+          d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
+          d.out_contig = 1;
+        }
         if (p2 > 1) { /* peer a owns z in [a*F3, ..): offt-compute.c:1015-1027 */
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
         }
-        d.out_contig = 1;
-        if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s)) return -1;
+        if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], sA)) return -1;
       }
-      be->event_record(st->ev_k1[r], s);
+      be->event_record(st->ev_k1[r], sA);
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
       if (st->x1) {
         be->stream_wait(st->s_comm1, st->ev_k1[r]);
@@ -817,7 +836,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         for (int a = 0; a < p2; a++) {
           sp[a] = (char *)st->send1[r] + (size_t)a * st->blk1 * esz;
           rp[a] = (char *)st->recv1[r] + (size_t)a * st->blk1 * esz;
-          sb[a] = rb[a] = (size_t)myT * c->M2 * c->M3 * esz;
+          sb[a] = rb[a] = (size_t)(st->slab_zyx ? T : myT) * c->M2 * c->M3 * esz;
         }
         if (myT > 0 && be->a2a(st, 1, p2, peers1, sp, sb, rp, rb, st->s_comm1)) return -1;
         be->event_record(st->ev_a1[r], st->s_comm1);
@@ -832,18 +851,28 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       if (myT > 0 && c->m3 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Ny, dir, 1);
-        d.ncols = c->m3; d.nb1 = myT;
-        d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3;
+        void *k2dst;
+        if (st->slab_zyx) {
+          /* recv1 block [z_l][y_l][x_t] -> recv2 [z_l][y][x]: columns = x of this tile */
+          d.ncols = myT; d.nb1 = c->m3;
+          d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T;
+          d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1;
+          k2dst = (char *)st->recv2 + (size_t)x0 * esz;
+        } else {
+          d.ncols = c->m3; d.nb1 = myT;
+          d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3;
+          d.out_axis_stride = c->M3; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M3;
+          if (p1 > 1) {
+            d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
+            d.out_block_stride = (long long)st->blk2;
+          }
+          k2dst = (char *)st->send2 + (size_t)x0 * c->M4 * c->M3 * esz;
+        }
         if (p2 > 1) {
           d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0;
           d.in_block_stride = (long long)st->blk1;
         }
-        d.out_axis_stride = c->M3; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M3;
-        if (p1 > 1) {
-          d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
-          d.out_block_stride = (long long)st->blk2;
-        }
-        if (be->pass(&d, st->recv1[r], (char *)st->send2 + (size_t)x0 * c->M4 * c->M3 * esz, s)) return -1;
+        if (be->pass(&d, st->recv1[r], k2dst, s)) return -1;
       }
       be->event_record(st->ev_k2[r], s);
       /* ---- a2a2(k) over comm2: x-tile k of every column block ---- */
@@ -875,11 +904,17 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     desc_init(&d, st, Nx, dir, 0);
     d.ncols = c->m3; d.nb1 = c->m4;
     d.in_axis_stride = (long long)c->M4 * c->M3; d.in_col_stride = 1; d.in_b1_stride = c->M3;
+    if (st->slab_zyx) { /* recv2 [z_l][y][x] -> out [z][y][x]: whole contiguous lines both sides */
+      d.ncols = c->m4; d.nb1 = c->m3;
+      d.in_axis_stride = 1; d.in_col_stride = c->M1; d.in_b1_stride = (long long)c->M4 * c->M1;
+      d.in_contig = 1;
+    }
     if (p1 > 1) {
       d.in_split = c->F1; d.in_split_nfloor = c->b1 ? p1 - c->b1 : 0;
       d.in_block_stride = (long long)st->blk2;
     }
     d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
+    if (st->slab_zyx) { d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2]; }
     d.out_contig = (c->ostride[0] == 1);
     d.scale = st->out_scale;
     if (be->pass(&d, st->recv2, data, s)) return -1;

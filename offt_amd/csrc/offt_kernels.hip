@@ -54,6 +54,33 @@ template <> struct vec2<float> { using type = float2; };
 
 template <typename T> struct cx { T x, y; };
 
+// global memory access helpers: 16-B (f64) / 8-B (f32) per lane.  Every element is
+// touched exactly once per pass, so loads and stores are non-temporal (streaming): A/B on
+// 1024^3 (profiles/r01_sweep.txt): -6 % transform time vs default cache policy.
+// -DOFFT_NO_NT_LOAD / -DOFFT_NO_NT_STORE restore the default policy for A/B builds.
+template <typename V2>
+__device__ __forceinline__ V2 gload(const V2 *p) {
+#ifndef OFFT_NO_NT_LOAD
+  using E = decltype(p->x);
+  typedef E vt __attribute__((ext_vector_type(2)));
+  vt r = __builtin_nontemporal_load(reinterpret_cast<const vt *>(p));
+  V2 o; o.x = r.x; o.y = r.y; return o;
+#else
+  return *p;
+#endif
+}
+template <typename V2>
+__device__ __forceinline__ void gstore(V2 *p, V2 v) {
+#ifndef OFFT_NO_NT_STORE
+  using E = decltype(p->x);
+  typedef E vt __attribute__((ext_vector_type(2)));
+  vt r; r.x = v.x; r.y = v.y;
+  __builtin_nontemporal_store(r, reinterpret_cast<vt *>(p));
+#else
+  *p = v;
+#endif
+}
+
 template <int B, int E_, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (B < E_) {
@@ -211,7 +238,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       const int n = j + u * TPL + t * (N / R0);
       V2 val;
       val.x = 0; val.y = 0;
-      if (valid) val = src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis];
+      if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
       v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
     });
   }
@@ -319,54 +346,10 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         V2 w;
         w.x = x.x * sc;
         w.y = (a.conj ? -x.y : x.y) * sc;
-        if (valid) dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis] = w;
+        if (valid) gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
       });
     }
   });
-}
-
-// ---------------------------------------------------------------------------
-// Developer probe: the same panel addressing as fft_panel_k with the butterflies
-// and the LDS exchange removed (results are NOT a transform).  It measures the
-// HBM ceiling of a pass's access pattern; enabled with OFFT_COPY_ONLY=1 and used
-// only by tools/dev_perf.py.
-// ---------------------------------------------------------------------------
-template <typename T, int N, int E, int COLS, bool INC, bool OUTC>
-__global__ void __launch_bounds__((N / E) * COLS)
-panel_copy_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out) {
-  using V2 = typename vec2<T>::type;
-  constexpr int TPL = N / E;
-  const int tid = threadIdx.x;
-  const unsigned bid = blockIdx.x;
-  const int cp = bid % (unsigned)a.ncp;
-  const unsigned rest = bid / (unsigned)a.ncp;
-  const int b1 = rest % (unsigned)a.nb1;
-  const int b2 = rest / (unsigned)a.nb1;
-  const int c0 = cp * COLS;
-  V2 v[E];
-  int c, j;
-  if constexpr (INC) { j = tid % TPL; c = tid / TPL; } else { c = tid % COLS; j = tid / COLS; }
-  {
-    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
-    const int mask = (int)((1u << a.in_shift) - 1u);
-    static_for<0, E>([&](auto ii) {
-      const int n = j + decltype(ii)::value * TPL;
-      v[decltype(ii)::value] = src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis];
-    });
-  }
-  if constexpr (INC != OUTC) {
-    // a transposing pass changes which thread owns which element; emulate the exchange's
-    // barrier cost-free by simply re-mapping (data values are meaningless here)
-    if constexpr (OUTC) { j = tid % TPL; c = tid / TPL; } else { c = tid % COLS; j = tid / COLS; }
-  }
-  {
-    V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
-    const int mask = (int)((1u << a.out_shift) - 1u);
-    static_for<0, E>([&](auto ii) {
-      const int n = j + decltype(ii)::value * TPL;
-      dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis] = v[decltype(ii)::value];
-    });
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -720,18 +703,6 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
       if (v->lds > 48 * 1024)
         HIPK_CHECK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
       v->attr_set = true;
-    }
-    static const int copy_only = getenv("OFFT_COPY_ONLY") ? atoi(getenv("OFFT_COPY_ONLY")) : 0;
-    if (copy_only && d->n == 1024 && d->precision == OFFT_PREC_F64) {
-      a.ncp = (d->ncols + 7) / 8;
-      nblk = (long long)a.ncp * d->nb1 * d->nb2;
-      const void *fn = d->in_contig ? (d->out_contig ? (const void *)panel_copy_k<double, 1024, 16, 8, true, true>
-                                                     : (const void *)panel_copy_k<double, 1024, 16, 8, true, false>)
-                                    : (d->out_contig ? (const void *)panel_copy_k<double, 1024, 16, 8, false, true>
-                                                     : (const void *)panel_copy_k<double, 1024, 16, 8, false, false>);
-      void *cargs[] = {(void *)&a, (void *)&in, (void *)&out};
-      HIPK_CHECK(hipLaunchKernel(fn, dim3((unsigned)nblk), dim3(512), cargs, 0, st));
-      return 0;
     }
     void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tb.quarter};
     HIPK_CHECK(hipLaunchKernel(v->fn, dim3((unsigned)nblk), dim3(v->threads), args, v->lds, st));

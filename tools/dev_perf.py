@@ -34,11 +34,9 @@ def run(N, S, eq, variants=(-1, -1, -1), prec=api.F64, reps=4):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    if len(sys.argv) > 2 and sys.argv[2] == "copy":
-        os.environ["OFFT_COPY_ONLY"] = "1"
-        print("COPY ONLY (pattern ceiling, not a transform)")
-        for S, eq in ((1, 0), (0, 0), (0, 1)):
-            run(N, S, eq)
+    if len(sys.argv) > 2 and sys.argv[2] == "zyx":
+        for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+            run(N, 0, 0, reps=6)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "wpad":
         for pad in (0, 8, 64, 72, 520, 1032, 4104):
