@@ -43,6 +43,10 @@ typedef struct offt_pass_desc {
   int in_contig, out_contig;
   int variant;    /* static-sweep variant id, -1 = default for this n           */
   double scale;   /* multiplied into the output (1.0 = unnormalised)            */
+  /* real-to-complex z pass (fftw_plan_dft_r2c_1d, offt-compute.c:334-336, 960-961):
+   * the input line holds n REAL values (unit stride, in_contig = 1, no split) at the
+   * start of a row of n/2+1 complex slots; only output indices 0..n/2 are stored. */
+  int real_input;
 } offt_pass_desc;
 
 /* Build device twiddle tables etc. for length n; call at plan time (allocates). */

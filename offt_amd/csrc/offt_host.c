@@ -461,10 +461,6 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   (void)in; (void)out;
   double t0 = wall_seconds();
   if (Nx < 1 || Ny < 1 || Nz < 1) { SET_ERR("offt_3d_init: bad grid %d %d %d", Nx, Ny, Nz); return NULL; }
-  if (is_r2c) {
-    SET_ERR("offt_3d_init: is_r2c=1 (real-to-complex z pass, offt-compute.c:334-336) is not built yet in the MI355X path");
-    return NULL;
-  }
   if (precision != OFFT_HIP_F64 && precision != OFFT_HIP_F32) { SET_ERR("bad precision %d", precision); return NULL; }
   struct _offt_plan *po = (struct _offt_plan *)calloc(1, sizeof *po);
   po->Nx = Nx; po->Ny = Ny; po->Nz = Nz;
@@ -522,7 +518,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
 
   if (!st->use_pipeline) {
     if (!po->params->v[_S_]) { /* transposed output layouts need one scratch volume */
-      st->work_elems = (size_t)Nx * ((size_t)Ny * Nz + (size_t)st->wpad);
+      st->work_elems = (size_t)Nx * ((size_t)Ny * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
     }
@@ -623,11 +619,14 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   hip_state *st = (hip_state *)po->hip_state;
   const offt_backend *be = st->be;
   const struct _offt_comm *c = po->comm;
-  const int Nx = po->Nx, Ny = po->Ny, Nz = po->Nz;
+  /* Nzf = length of the z transform; Nz = number of z values kept afterwards
+   * (Nz/2+1 for real-to-complex, offt-compute.c:63) -- every extent and stride below uses Nz */
+  const int Nx = po->Nx, Ny = po->Ny, Nzf = po->Nz, Nz = po->is_r2c ? po->Nz / 2 + 1 : po->Nz;
   const long long is0 = c->istride[0], is1 = c->istride[1];
   const long long os0 = c->ostride[0], os1 = c->ostride[1], os2 = c->ostride[2];
   void *s = st->s_compute;
   void *W = st->work;
+  if (po->is_r2c && dir > 0) { SET_ERR("complex-to-real inverse is not built (the reference has no inverse at all)"); return -1; }
   offt_pass_desc d[3];
   const void *src[3];
   void *dst[3];
@@ -637,7 +636,8 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 
   if (S) {
     /* x-y-z output == input layout: three in-place passes, strided along y and x */
-    desc_init(&d[0], st, Nz, dir, 2);
+    desc_init(&d[0], st, Nzf, dir, 2);
+    d[0].real_input = po->is_r2c;
     d[0].ncols = Ny; d[0].nb1 = Nx;
     d[0].in_axis_stride = d[0].out_axis_stride = 1;
     d[0].in_col_stride = d[0].out_col_stride = is1;
@@ -665,7 +665,8 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
      * this replaces FFTz + pack/unpack + setup_transpose's xzy->zxy permutation
      * + FFTy + FFTx of the reference (offt-compute.c:625-634, 4019-4036). */
     const long long wx = (long long)Nz * Ny + st->wpad; /* W plane (+ optional pad, elements) */
-    desc_init(&d[0], st, Nz, dir, 2);
+    desc_init(&d[0], st, Nzf, dir, 2);
+    d[0].real_input = po->is_r2c;
     desc_init(&d[1], st, Ny, dir, 1);
     desc_init(&d[2], st, Nx, dir, 0);
     if (dir < 0) {
@@ -704,7 +705,8 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
     /* y-z-x output (is_equalxy): z and y passes in the natural layout inside W,
      * the x pass transposes into the caller's layout */
     const long long w1 = Nz, w0 = (long long)Ny * Nz;
-    desc_init(&d[0], st, Nz, dir, 2);
+    desc_init(&d[0], st, Nzf, dir, 2);
+    d[0].real_input = po->is_r2c;
     d[0].ncols = Ny; d[0].nb1 = Nx; d[0].in_axis_stride = d[0].out_axis_stride = 1;
     d[0].in_contig = d[0].out_contig = 1;
     desc_init(&d[1], st, Ny, dir, 1);
@@ -808,6 +810,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       if (myT > 0 && c->m2 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Nz, dir, 2);
+        d.real_input = po->is_r2c;
         d.ncols = c->m2; d.nb1 = myT;
         d.in_axis_stride = 1; d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.in_contig = 1;
@@ -996,8 +999,13 @@ int offt_hip_device_synchronize(void) { HCHECK(hipDeviceSynchronize(), return -1
 int offt_hip_fill_input(struct _offt_plan *po, void *buf, int kind) {
   hip_state *st = (hip_state *)po->hip_state;
   const struct _offt_comm *c = po->comm;
-  int rc = offt_hipk_fill(buf, st->prec, kind, c->isize[0], c->isize[1], c->isize[2], c->istart[0], c->istart[1],
-                          c->istart[2], c->istride[0], c->istride[1], c->istride[2], st->s_compute);
+  int rc;
+  if (po->is_r2c) /* real rows: element (x,y,z) at scalar index z + 2*istride1*y + 2*istride0*x (run-fft.c:54) */
+    rc = offt_hipk_fill(buf, st->prec | 0x100, kind, c->isize[0], c->isize[1], c->isize[2], c->istart[0], c->istart[1],
+                        c->istart[2], 2LL * c->istride[0], 2LL * c->istride[1], 1, st->s_compute);
+  else
+    rc = offt_hipk_fill(buf, st->prec, kind, c->isize[0], c->isize[1], c->isize[2], c->istart[0], c->istart[1],
+                        c->istart[2], c->istride[0], c->istride[1], c->istride[2], st->s_compute);
   if (rc) { SET_ERR("%s", offt_hipk_last_error()); return rc; }
   return st->be->stream_sync(st->s_compute);
 }

@@ -192,7 +192,7 @@ __device__ __forceinline__ int padidx(int i) {
   else return i + (i >> SHIFT);
 }
 
-template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT>
+template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
 __global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
 fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
             const typename vec2<T>::type *twq) {
@@ -238,8 +238,14 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       const int n = j + u * TPL + t * (N / R0);
       V2 val;
       val.x = 0; val.y = 0;
-      if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
-      v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
+      if constexpr (R2C) {
+        // n real values at the head of the row: element n is the n-th T of the row
+        if (valid) val.x = reinterpret_cast<const T *>(src)[n];
+        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+      } else {
+        if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
+        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
+      }
     });
   }
 
@@ -346,7 +352,8 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         V2 w;
         w.x = x.x * sc;
         w.y = (a.conj ? -x.y : x.y) * sc;
-        if (valid) gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
+        if (valid && (!R2C || n <= N / 2))
+          gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
       });
     }
   });
@@ -365,6 +372,7 @@ struct GenArgs {
   int in_split, in_nfloor, out_split, out_nfloor;
   int n, ncols, nb1;
   int conj;
+  int real_in;
   double scale;
 };
 
@@ -397,12 +405,15 @@ dft_generic_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
   const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)c * a.in_col;
   V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)c * a.out_col;
   for (int n = threadIdx.x; n < a.n; n += blockDim.x) {
-    V2 x = src[split_off(n, a.in_split, a.in_nfloor, a.in_blk, a.in_axis)];
+    V2 x;
+    if (a.real_in) { x.x = reinterpret_cast<const T *>(src)[n]; x.y = 0; }
+    else x = src[split_off(n, a.in_split, a.in_nfloor, a.in_blk, a.in_axis)];
     if (a.conj) x.y = -x.y;
     line[n] = x;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < a.n; k += blockDim.x) {
+  const int kend = a.real_in ? a.n / 2 + 1 : a.n;
+  for (int k = threadIdx.x; k < kend; k += blockDim.x) {
     // accumulate in the working precision with compensated (Kahan) sums so the
     // O(N) summation error stays at the level of the O(log N) fast path
     T sr = 0, si = 0, cr = 0, ci = 0;
@@ -473,6 +484,19 @@ fill_k(V2 *buf, int kind, int n0, int n1, int n2, int s0, int s1, int s2,
   }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256)
+fill_real_k(T *buf, int kind, int n0, int n1, int n2, int s0, int s1, int s2, long long st0, long long st1, long long st2) {
+  long long total = (long long)n0 * n1 * n2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int i2 = (int)(i % n2);
+    long long r = i / n2;
+    int i1 = (int)(r % n1), i0 = (int)(r / n1);
+    buf[i0 * st0 + i1 * st1 + i2 * st2] = kind == 0 ? (T)((i2 + s2) + 10 * (i1 + s1) + 100 * (i0 + s0))
+                                                    : (T)hash_val(i0 + s0, i1 + s1, i2 + s2, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side: kernel registry, twiddle tables, launchers
 // ---------------------------------------------------------------------------
@@ -481,6 +505,7 @@ struct Variant {
   bool inc, outc;
   int id;
   bool is_default;  // default for this (n, prec, inc, outc) flavour
+  bool r2c;         // real-input z-pass instantiation
   int cols, threads;
   size_t lds;
   const void *fn;
@@ -504,13 +529,16 @@ void reg_variant(int id, int defmask = -1) {
   char nm[160];
   snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
            R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
-  auto add = [&](bool inc, bool outc, int bit, const void *fn) {
-    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, COLS, Cfg::NT, Cfg::LDS_BYTES, fn, nm, false});
+  auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::LDS_BYTES, fn, nm, false});
   };
   add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
   add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
   add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
   add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
+  // real-input z pass: only the contiguous-read flavours of the default variant need it
+  if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
+  if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
 }
 
 std::once_flag g_reg_once;
@@ -556,11 +584,11 @@ void build_registry() {
 #endif
 }
 
-Variant *find_variant(int n, int prec, bool inc, bool outc, int id) {
+Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false) {
   std::call_once(g_reg_once, build_registry);
   Variant *def = nullptr;
   for (auto &v : registry()) {
-    if (v.n == n && v.prec == prec && v.inc == inc && v.outc == outc) {
+    if (v.n == n && v.prec == prec && v.inc == inc && v.outc == outc && v.r2c == r2c) {
       if (v.id == id) return &v;
       if (v.is_default) def = &v;
     }
@@ -632,7 +660,8 @@ int get_tables(int n, int prec, Tables &out, bool create) {
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 bool fast_ok(const offt_pass_desc *d) {
-  if (!find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1)) return false;
+  if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return false;
+  if (!find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0)) return false;
   if (d->in_split_nfloor > 0 || d->out_split_nfloor > 0) return false;
   if (d->in_split && !is_pow2(d->in_split)) return false;
   if (d->out_split && !is_pow2(d->out_split)) return false;
@@ -655,7 +684,7 @@ int offt_hipk_variant_count(int n, int precision) {
   std::call_once(g_reg_once, build_registry);
   int c = 0;
   for (auto &v : registry())
-    if (v.n == n && v.prec == precision && v.inc && v.outc) c = v.id + 1 > c ? v.id + 1 : c;
+    if (v.n == n && v.prec == precision && v.inc && v.outc && !v.r2c) c = v.id + 1 > c ? v.id + 1 : c;
   return c;
 }
 
@@ -685,7 +714,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
   if (fast_ok(d)) {
-    Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, d->variant);
+    Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, d->real_input ? -1 : d->variant, d->real_input != 0);
     PassArgs a;
     a.in_axis = d->in_axis_stride; a.in_col = d->in_col_stride; a.in_b1 = d->in_b1_stride; a.in_b2 = d->in_b2_stride;
     a.out_axis = d->out_axis_stride; a.out_col = d->out_col_stride; a.out_b1 = d->out_b1_stride; a.out_b2 = d->out_b2_stride;
@@ -717,6 +746,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   g.out_split = d->out_split; g.out_nfloor = d->out_split_nfloor;
   g.n = d->n; g.ncols = d->ncols; g.nb1 = d->nb1;
   g.conj = d->direction > 0;
+  g.real_in = d->real_input;
   g.scale = d->scale;
   long long nblk = (long long)d->ncols * d->nb1 * d->nb2;
   if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
@@ -768,6 +798,16 @@ int offt_hipk_fill(void *buf, int precision, int kind, int n0, int n1, int n2, i
   if (total <= 0) return 0;
   long long nb = (total + 255) / 256;
   if (nb > 256 * 64) nb = 256 * 64;
+  if (precision & 0x100) {  // real-valued field (r2c input), strides in scalars
+    if ((precision & 0xff) == OFFT_PREC_F64)
+      hipLaunchKernelGGL(fill_real_k<double>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (double *)buf, kind,
+                         n0, n1, n2, s0, s1, s2, st0, st1, st2);
+    else
+      hipLaunchKernelGGL(fill_real_k<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float *)buf, kind,
+                         n0, n1, n2, s0, s1, s2, st0, st1, st2);
+    HIPK_CHECK(hipGetLastError());
+    return 0;
+  }
   if (precision == OFFT_PREC_F64)
     hipLaunchKernelGGL(fill_k<double2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (double2 *)buf, kind,
                        n0, n1, n2, s0, s1, s2, st0, st1, st2);

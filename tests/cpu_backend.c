@@ -45,12 +45,13 @@ static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
         for (int k = 0; k < n; k++) {
           long long o = ib + split_off(k, d->in_split, d->in_split_nfloor, d->in_block_stride, d->in_axis_stride);
           double re, im;
-          if (f32) { re = ((const float *)in)[2 * o]; im = ((const float *)in)[2 * o + 1]; }
+          if (d->real_input) { re = f32 ? ((const float *)in)[2 * ib + k] : ((const double *)in)[2 * ib + k]; im = 0.0; }
+          else if (f32) { re = ((const float *)in)[2 * o]; im = ((const float *)in)[2 * o + 1]; }
           else { re = ((const double *)in)[2 * o]; im = ((const double *)in)[2 * o + 1]; }
           line[2 * k] = re; line[2 * k + 1] = d->direction > 0 ? -im : im;
         }
         orc_fft_execute(pl, line, 1, 0, 1, scr);
-        for (int k = 0; k < n; k++) {
+        for (int k = 0; k < (d->real_input ? n / 2 + 1 : n); k++) {
           long long o = ob + split_off(k, d->out_split, d->out_split_nfloor, d->out_block_stride, d->out_axis_stride);
           double re = line[2 * k] * d->scale, im = (d->direction > 0 ? -line[2 * k + 1] : line[2 * k + 1]) * d->scale;
           if (f32) { ((float *)out)[2 * o] = (float)re; ((float *)out)[2 * o + 1] = (float)im; }

@@ -78,10 +78,10 @@ def uninstall():
     L.offt_hip_test_set_backend(None, 0, 1)
 
 
-def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, **params):
+def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, is_r2c=0, **params):
     """init + fill this rank's block on the host + execute; returns (comm dict, params, local result array)."""
     cp = api.make_params(**params)
-    po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision)
+    po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision, is_r2c=is_r2c)
     c = api.comm_dict(po)
     v = list(po.contents.params.contents.v)
     n = api.local_elems(po)
@@ -92,8 +92,13 @@ def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, 
         f = O.hash_field(i0, i1, i2, c["istart"][0], c["istart"][1], c["istart"][2]) if kind else \
             O.ramp_field(Nx, Ny, Nz)[c["istart"][0]:c["istart"][0] + i0, c["istart"][1]:c["istart"][1] + i1, :]
         s0, s1, s2 = c["istride"]
-        idx = np.arange(i0)[:, None, None] * s0 + np.arange(i1)[None, :, None] * s1 + np.arange(i2)[None, None, :] * s2
-        buf[idx.ravel()] = f.astype(ct).ravel()
+        if is_r2c:  # real rows: scalar index z + 2*istride1*y + 2*istride0*x (run-fft.c:54)
+            rv = buf.view(np.float64 if precision == api.F64 else np.float32)
+            idx = np.arange(i0)[:, None, None] * 2 * s0 + np.arange(i1)[None, :, None] * 2 * s1 + np.arange(i2)[None, None, :]
+            rv[idx.ravel()] = f.real.ravel()
+        else:
+            idx = np.arange(i0)[:, None, None] * s0 + np.arange(i1)[None, :, None] * s1 + np.arange(i2)[None, None, :] * s2
+            buf[idx.ravel()] = f.astype(ct).ravel()
     ptr = buf.ctypes.data_as(C.c_void_p)
     api.offt_3d_execute_dir(po, ptr, ptr, direction)
     api.offt_3d_fin(po)

@@ -31,10 +31,23 @@ def read_output(po, dev, shape, precision=api.F64):
     return res[idx].reshape(shape)
 
 
-def gpu_fft(shape, field=None, is_equalxy=0, precision=api.F64, **params):
+def gpu_fft(shape, field=None, is_equalxy=0, precision=api.F64, is_r2c=0, **params):
     field = O.hash_field(*shape) if field is None else field
-    po = api.offt_3d_init(*shape, custom_params=api.make_params(**params), is_equalxy=is_equalxy, precision=precision)
+    po = api.offt_3d_init(*shape, custom_params=api.make_params(**params), is_equalxy=is_equalxy, precision=precision,
+                          is_r2c=is_r2c)
     try:
+        if is_r2c:
+            c = api.comm_dict(po)
+            ct = np.complex128 if precision == api.F64 else np.complex64
+            buf = np.zeros(api.local_elems(po), dtype=ct)
+            rv = buf.view(np.float64 if precision == api.F64 else np.float32)
+            s0, s1, _ = c["istride"]
+            n0, n1, n2 = shape
+            idx = (np.arange(n0)[:, None, None] * 2 * s0 + np.arange(n1)[None, :, None] * 2 * s1 + np.arange(n2)[None, None, :]).ravel()
+            rv[idx] = field.real.ravel()
+            dev = torch.from_numpy(rv).cuda()
+            api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+            return read_output(po, dev, (n0, n1, n2 // 2 + 1), precision), c
         dev, _ = make_input(po, field, precision)
         api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
         return read_output(po, dev, shape, precision), api.comm_dict(po)

@@ -226,3 +226,23 @@ def test_rccl_self_exchange_one_rank(built, monkeypatch):
             check64(got, want)
     finally:
         L.offt_hip_finalize_world()
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (64, 64, 64), (128, 32, 256), (32, 32, 1024), (20, 12, 18), (8, 8, 2)])
+def test_r2c(built, shape):
+    """real-to-complex (-R): z pass real -> Nz/2+1 complex, then y and x on the half spectrum"""
+    for layout in (dict(S=1), dict()):
+        got, c = gpu_fft(shape, is_r2c=1, **layout)
+        want, comms, _ = O.world_fft(*shape, 1, kind=1, is_r2c=1, **layout)
+        check64(got, want)
+        assert c["ostride"] == comms[0]["ostride"] and c["istride"] == comms[0]["istride"]
+    got, _ = gpu_fft(shape, is_r2c=1, precision=api.F32)
+    assert rel(got.astype(np.complex128), np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2))) < TOL32
+
+
+def test_r2c_forced_pipeline(built, monkeypatch):
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    for shape, kw in [((64, 64, 64), dict(T1=8, W1=2)), ((32, 16, 30), dict(T1=5, W1=1, S=1))]:
+        got, _ = gpu_fft(shape, is_r2c=1, **kw)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, is_r2c=1, **kw)
+        check64(got, want)

@@ -72,6 +72,20 @@ def test_forced_self_exchange(cpu1, monkeypatch):
         assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, (shape, kw)
 
 
+@pytest.mark.parametrize("shape", [(8, 8, 8), (4, 6, 10), (16, 4, 7)])
+@pytest.mark.parametrize("layout", [dict(S=1), dict()])
+def test_r2c_single_rank(cpu1, shape, layout):
+    """real-to-complex z pass (-R, offt-compute.c:334-336, 960-961; run-fft.c:53-54)"""
+    c, v, buf = cpu_world.run_rank(*shape, is_r2c=1, **layout)
+    G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
+    cpu_world.scatter_out(c, buf, G)
+    assert rel(G, np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2))) < TOL
+    oc = O.comm(*shape, 1, 0, 1, 1, 0, layout.get("S", 0))
+    for k in oc:
+        if k in c:
+            assert c[k] == oc[k], k
+
+
 def test_inverse_roundtrip_single(cpu1):
     for shape, kw in [((8, 4, 16), dict(S=1)), ((8, 8, 6), dict())]:
         cp = api.make_params(**kw)
@@ -134,19 +148,22 @@ def _run_world(size, cases, tmp_path):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r]}"
     for ci, case in enumerate(cases):
         shape = tuple(case["N"])
-        G = np.full(shape, np.nan + 0j)
+        r2c = case.get("r2c", 0)
+        oshape = (shape[0], shape[1], shape[2] // 2 + 1) if r2c else shape
+        G = np.full(oshape, np.nan + 0j)
         for r in range(size):
             meta = json.load(open(tmp_path / f"case{ci}_rank{r}.json"))
             buf = np.load(tmp_path / f"case{ci}_rank{r}.npy")
             cpu_world.scatter_out(meta["comm"], buf, G)
-            oc = O.comm(*shape, size, r, meta["v"][0], 0, case.get("eq", 0), meta["v"][23])
+            oc = O.comm(*shape, size, r, meta["v"][0], r2c, case.get("eq", 0), meta["v"][23])
             for k in oc:
                 if k in meta["comm"]:
                     assert meta["comm"][k] == oc[k], (case, r, k)
         assert not np.isnan(G).any(), case
-        assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, case
+        want = np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2)) if r2c else np.fft.fftn(O.hash_field(*shape))
+        assert rel(G, want) < TOL, case
         # and against the restated reference pipeline on the same decomposition
-        og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), **case["params"])
+        og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **case["params"])
         assert rel(G, og) < TOL, case
 
 
@@ -154,7 +171,8 @@ def test_gloo_world2(built, tmp_path):
     cases = [dict(N=[8, 8, 8], params=dict(P1=1)), dict(N=[8, 8, 8], params=dict(P1=2)),
              dict(N=[8, 8, 8], params=dict(P1=1, S=1, T1=2, W1=1)), dict(N=[8, 8, 8], params=dict(P1=2), eq=1),
              dict(N=[9, 7, 5], params=dict(P1=2, T1=2, W1=2)), dict(N=[9, 7, 5], params=dict(P1=1, T1=4, W1=0, S=1)),
-             dict(N=[16, 16, 4], params=dict())]
+             dict(N=[16, 16, 4], params=dict()),
+             dict(N=[8, 8, 8], params=dict(P1=1), r2c=1), dict(N=[8, 6, 12], params=dict(P1=2, S=1), r2c=1)]
     _run_world(2, cases, tmp_path)
 
 
