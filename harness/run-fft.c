@@ -31,13 +31,18 @@ static double now(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void host_ramp(double *in, const struct _offt_comm *c) { /* run-fft.c:46-61 */
+static void host_ramp(double *in, const struct _offt_comm *c, int is_r2c) { /* run-fft.c:46-61 */
   for (int x = 0; x < c->isize[0]; x++)
     for (int y = 0; y < c->isize[1]; y++)
       for (int z = 0; z < c->isize[2]; z++) {
-        size_t o = 2 * ((size_t)z + (size_t)c->istride[1] * y + (size_t)c->istride[0] * x);
-        in[o] = z + 10 * (y + c->istart[1]) + 100 * (x + c->istart[0]);
-        in[o + 1] = 0.0;
+        double v = z + 10 * (y + c->istart[1]) + 100 * (x + c->istart[0]);
+        if (is_r2c) {
+          in[(size_t)z + 2 * (size_t)c->istride[1] * y + 2 * (size_t)c->istride[0] * x] = v;
+        } else {
+          size_t o = 2 * ((size_t)z + (size_t)c->istride[1] * y + (size_t)c->istride[0] * x);
+          in[o] = v;
+          in[o + 1] = 0.0;
+        }
       }
 }
 
@@ -129,7 +134,7 @@ int main(int argc, char **argv) {
   double t_min = 999999999.0, t_min_arr[GES];
   memset(t_min_arr, 0, sizeof t_min_arr);
   for (int r = 0; r < reps; r++) {
-    if (host_data) host_ramp(out, po->comm); else offt_hip_fill_input(po, out, 0);
+    if (host_data) host_ramp(out, po->comm, is_r2c); else offt_hip_fill_input(po, out, 0);
 #ifdef OFFT_HARNESS_MPI
     MPI_Barrier(MPI_COMM_WORLD);
 #endif
@@ -143,7 +148,7 @@ int main(int argc, char **argv) {
   double spot[4][2];
   int nspot = 0;
   if (verbose && rank == 0) { /* run-fft.c:452-503: out[x=0, y=0, z=0..3] through ostride */
-    int MM3 = Nz / (p / p1), zEnd = 4 > MM3 ? MM3 : 4;
+    int MM3 = (is_r2c ? Nz / 2 + 1 : Nz) / (p / p1), zEnd = 4 > MM3 ? MM3 : 4;
     for (int z = 0; z < zEnd; z++) {
       size_t o = 2 * (size_t)z * po->comm->ostride[2];
       if (host_data) { spot[z][0] = out[o]; spot[z][1] = out[o + 1]; }
@@ -152,7 +157,7 @@ int main(int argc, char **argv) {
     }
   }
   double tf = -now();
-  int MM3p = Nz / (p / p1), MM4p = Ny / p1;
+  int MM3p = (is_r2c ? Nz / 2 + 1 : Nz) / (p / p1), MM4p = Ny / p1;
   offt_3d_fin(po);
   tf += now();
   t += tf;

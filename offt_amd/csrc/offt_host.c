@@ -325,7 +325,6 @@ typedef struct hip_state {
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
-  int zchunk;
   int wpad;
   int async;
   double last_dev_s, pass_s[3];
@@ -496,7 +495,6 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   /* scratch planes are offset by an odd number of 128-B lines so that the 8 x-planes a
    * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt) */
   st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : 72;
-  st->zchunk = getenv("OFFT_ZCHUNK") ? atoi(getenv("OFFT_ZCHUNK")) : 0;
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
   if (!g_backend) {
@@ -560,10 +558,17 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
        * (stride p2) -- offt-compute.c:78-125 */
       if (!G.have_comm) { SET_ERR("offt_3d_init: world of %d ranks but no RCCL communicator (offt_hip_set_world)", po->p); goto fail; }
       int rx = po->rank / p2, ry = po->rank % p2;
-      if (st->x1) { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), goto fail); st->have_comm1 = 1; }
-      else        { ncclComm_t tmp; NCHECK(R.CommSplit(G.world, -1, 0, &tmp, NULL), goto fail); }
-      if (st->x2) { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), goto fail); st->have_comm2 = 1; }
-      else        { ncclComm_t tmp; NCHECK(R.CommSplit(G.world, -1, 0, &tmp, NULL), goto fail); }
+      /* a group that spans the whole world (slab shapes 1 x p, p x 1) simply uses the world
+       * communicator: peer index == world rank.  Real sub-groups are split off; every rank
+       * makes the same sequence of collective ncclCommSplit calls. */
+      if (st->x1) {
+        if (p2 == po->p) st->comm1 = G.world;
+        else { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), goto fail); st->have_comm1 = 1; }
+      }
+      if (st->x2) {
+        if (p1 == po->p && !(st->x1 && p2 == po->p)) st->comm2 = G.world; /* never share one comm between the two comm streams */
+        else { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), goto fail); st->have_comm2 = 1; }
+      }
     }
   }
   po->t_init[INIT_BUFFER] = wall_seconds() - tb0;
@@ -734,26 +739,6 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   }
   d[2].scale = st->out_scale; /* last launch */
   for (int i = 0; i < 3; i++) st->pass_slot[i] = slot[i];
-  if (zyx && dir < 0 && st->zchunk > 0 && st->zchunk < Nz) {
-    /* Infinity-Cache blocking: run P2 and P3 back to back on slabs of `zchunk`
-     * z-planes, so that P3 finds the slab P2 just wrote still in the 256 MiB
-     * last-level cache instead of re-reading it from HBM. */
-    be->event_record(st->evp[0], s);
-    if (be->pass(&d[0], src[0], dst[0], s)) return -1;
-    be->event_record(st->evp[1], s);
-    for (int z0 = 0; z0 < Nz; z0 += st->zchunk) {
-      const int nz = (Nz - z0 < st->zchunk) ? Nz - z0 : st->zchunk;
-      offt_pass_desc a = d[1], b = d[2];
-      a.nb1 = nz; b.nb1 = nz;
-      const char *s1 = (const char *)src[1] + (size_t)z0 * d[1].in_b1_stride * st->esz;
-      char *o1 = (char *)dst[1] + (size_t)z0 * d[1].out_b1_stride * st->esz;
-      if (be->pass(&a, s1, o1, s)) return -1;
-      if (be->pass(&b, o1, o1, s)) return -1;
-    }
-    be->event_record(st->evp[2], s);
-    be->event_record(st->evp[3], s);
-    return 0;
-  }
   for (int i = 0; i < 3; i++) {
     be->event_record(st->evp[i], s);
     if (be->pass(&d[i], src[i], dst[i], s)) return -1;
@@ -789,7 +774,6 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   const int Nx = po->Nx, Ny = po->Ny, Nz = po->Nz;
   const size_t esz = st->esz;
   void *s = st->s_compute;
-  const int rx = po->rank / p2;
   int peers1[p2 > 0 ? p2 : 1], peers2[p1 > 0 ? p1 : 1];
   for (int a = 0; a < p2; a++) peers1[a] = a; /* key = rank_y inside comm1 */
   for (int a = 0; a < p1; a++) peers2[a] = a; /* key = rank_x inside comm2 */
@@ -900,7 +884,6 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     be->stream_wait(s, st->ev_a2_last);
   }
   be->event_record(st->evp[2], s);
-  (void)rx;
   /* ---- K3: unpack2 + FFTx into the caller's layout (offt-compute.c:2347-2993) ---- */
   if (c->m4 > 0 && c->m3 > 0) {
     offt_pass_desc d;
@@ -923,7 +906,6 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     if (be->pass(&d, st->recv2, data, s)) return -1;
   }
   be->event_record(st->evp[3], s);
-  (void)Ny;
   return 0;
 }
 

@@ -360,19 +360,34 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 }
 
 // ---------------------------------------------------------------------------
-// Generic any-length kernel: DFT by definition from an LDS-staged line with an
-// exact twiddle table (w_N^m, m = 0..N-1, in global memory).  O(N^2) per line;
-// it exists so that every length the reference accepts (FFTW handles any N)
-// produces correct results; power-of-two lengths never come here.
-// One workgroup per line; threads loop over output indices.
+// Any-length kernel: mixed-radix Stockham in LDS with run-time radices.
+// It exists so that every length the reference accepts (FFTW takes any N) is
+// transformed correctly and at a tolerable cost; lengths with a compile-time
+// register kernel never come here, nor do power-of-two splits.
+//
+// N = r0 * r1 * ... (prime factors, pairs of 2 merged to 4).  One workgroup owns
+// COLS lines in two ping-pong LDS images.  A work item of stage s produces ONE
+// output of one radix-r butterfly:
+//   y[(q-k) r + k + j Ns] = sum_t x[q + t N/r] * w_N^(k t M) * w_r^(j t),
+//   k = q mod Ns, M = N / (Ns r)
+// i.e. r complex multiply-adds with exact table twiddles w_N^m (m = 0..N-1,
+// staged in LDS when it fits).  Cost N * sum(r_s) per line instead of N^2; a
+// prime N degenerates to one stage of radix N (the plain DFT).
+// Also handles the reference's uneven A2AV per-peer splits on either side and
+// the real-input z pass.
 // ---------------------------------------------------------------------------
+#define OFFT_MIX_MAXFAC 16
 struct GenArgs {
   long long in_axis, in_col, in_b1, in_b2, in_blk;
   long long out_axis, out_col, out_b1, out_b2, out_blk;
   int in_split, in_nfloor, out_split, out_nfloor;
-  int n, ncols, nb1;
+  int n, ncols, nb1, ncp, cols;
+  int in_contig, out_contig;
   int conj;
   int real_in;
+  int tw_in_lds;
+  int nfac;
+  int fac[OFFT_MIX_MAXFAC];
   double scale;
 };
 
@@ -392,46 +407,85 @@ __device__ __forceinline__ long long split_off(int k, int split, int nfloor, lon
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-dft_generic_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
-              const typename vec2<T>::type *twf) {
+fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
+            const typename vec2<T>::type *twf) {
   using V2 = typename vec2<T>::type;
   extern __shared__ __align__(16) unsigned char smem[];
-  V2 *line = reinterpret_cast<V2 *>(smem);
+  const int N = a.n, C = a.cols;
+  V2 *buf0 = reinterpret_cast<V2 *>(smem);
+  V2 *buf1 = buf0 + (size_t)C * N;
+  V2 *twl = buf1 + (size_t)C * N;
+  const V2 *tw = a.tw_in_lds ? twl : twf;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const unsigned bid = blockIdx.x;
-  const int c = bid % (unsigned)a.ncols;
-  const unsigned rest = bid / (unsigned)a.ncols;
+  const int cp = bid % (unsigned)a.ncp;
+  const unsigned rest = bid / (unsigned)a.ncp;
   const int b1 = rest % (unsigned)a.nb1;
   const int b2 = rest / (unsigned)a.nb1;
-  const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)c * a.in_col;
-  V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)c * a.out_col;
-  for (int n = threadIdx.x; n < a.n; n += blockDim.x) {
+  const int c0 = cp * C;
+  const int nc = (a.ncols - c0 < C) ? a.ncols - c0 : C;  // valid columns of this panel
+  const long long ibase = (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2;
+  const long long obase = (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2;
+
+  if (a.tw_in_lds)
+    for (int i = tid; i < N; i += NT) twl[i] = twf[i];
+  for (int i = tid; i < nc * N; i += NT) {
+    int c, n;
+    if (a.in_contig) { n = i % N; c = i / N; } else { c = i % nc; n = i / nc; }
+    const V2 *src = in + ibase + (long long)(c0 + c) * a.in_col;
     V2 x;
     if (a.real_in) { x.x = reinterpret_cast<const T *>(src)[n]; x.y = 0; }
     else x = src[split_off(n, a.in_split, a.in_nfloor, a.in_blk, a.in_axis)];
     if (a.conj) x.y = -x.y;
-    line[n] = x;
+    buf0[c * N + n] = x;
   }
   __syncthreads();
-  const int kend = a.real_in ? a.n / 2 + 1 : a.n;
-  for (int k = threadIdx.x; k < kend; k += blockDim.x) {
-    // accumulate in the working precision with compensated (Kahan) sums so the
-    // O(N) summation error stays at the level of the O(log N) fast path
-    T sr = 0, si = 0, cr = 0, ci = 0;
-    int m = 0;
-    for (int n = 0; n < a.n; ++n) {
-      V2 w = twf[m];
-      V2 x = line[n];
-      T pr = x.x * w.x - x.y * w.y;
-      T pi = x.x * w.y + x.y * w.x;
-      T yr = pr - cr, tr = sr + yr; cr = (tr - sr) - yr; sr = tr;
-      T yi = pi - ci, ti = si + yi; ci = (ti - si) - yi; si = ti;
-      m += k;
-      if (m >= a.n) m -= a.n;
+
+  V2 *x = buf0, *y = buf1;
+  int Ns = 1;
+  for (int s = 0; s < a.nfac; ++s) {
+    const int r = a.fac[s];
+    const int nq = N / r;        // butterflies per line
+    const int M = N / (Ns * r);  // twiddle step
+    for (int i = tid; i < nc * N; i += NT) {
+      const int c = i / N;
+      const int o = i - c * N;   // (q, j) of this output
+      const int q = o % nq, j = o / nq;
+      const int k = q % Ns;
+      const V2 *xc = x + c * N + q;
+      T sr = 0, si = 0;
+      int e1 = 0;                // k * t * M       (< N)
+      int jt = 0;                // (j * t) mod r
+      const int kM = k * M;
+      for (int t = 0; t < r; ++t) {
+        int e = e1 + jt * nq;    // + (N/r) * ((j t) mod r)
+        if (e >= N) e -= N;
+        const V2 w = tw[e];
+        const V2 v = xc[t * nq];
+        sr += v.x * w.x - v.y * w.y;
+        si += v.x * w.y + v.y * w.x;
+        e1 += kM;
+        jt += j;
+        if (jt >= r) jt -= r;
+      }
+      V2 res; res.x = sr; res.y = si;
+      y[c * N + (q - k) * r + k + j * Ns] = res;
     }
-    V2 y;
-    y.x = sr * (T)a.scale;
-    y.y = (a.conj ? -si : si) * (T)a.scale;
-    dst[split_off(k, a.out_split, a.out_nfloor, a.out_blk, a.out_axis)] = y;
+    __syncthreads();
+    V2 *tmp = x; x = y; y = tmp;
+    Ns *= r;
+  }
+
+  const int kend = a.real_in ? N / 2 + 1 : N;
+  for (int i = tid; i < nc * kend; i += NT) {
+    int c, k;
+    if (a.out_contig) { k = i % kend; c = i / kend; } else { c = i % nc; k = i / nc; }
+    V2 v = x[c * N + k];
+    V2 w;
+    w.x = v.x * (T)a.scale;
+    w.y = (a.conj ? -v.y : v.y) * (T)a.scale;
+    V2 *dst = out + obase + (long long)(c0 + c) * a.out_col;
+    dst[split_off(k, a.out_split, a.out_nfloor, a.out_blk, a.out_axis)] = w;
   }
 }
 
@@ -690,11 +744,11 @@ int offt_hipk_variant_count(int n, int precision) {
 
 const char *offt_hipk_variant_name(int n, int precision, int variant) {
   Variant *v = find_variant(n, precision, true, true, variant);
-  return v ? v->name.c_str() : "generic-dft";
+  return v ? v->name.c_str() : "mixed-radix any-length";
 }
 
 const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
-  if (!fast_ok(d)) return "dft_generic_k";
+  if (!fast_ok(d)) return "fft_mixed_k";
   return "fft_panel_k";
 }
 
@@ -737,7 +791,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     HIPK_CHECK(hipLaunchKernel(v->fn, dim3((unsigned)nblk), dim3(v->threads), args, v->lds, st));
     return 0;
   }
-  // generic path
+  // any-length path
   GenArgs g;
   g.in_axis = d->in_axis_stride; g.in_col = d->in_col_stride; g.in_b1 = d->in_b1_stride; g.in_b2 = d->in_b2_stride;
   g.out_axis = d->out_axis_stride; g.out_col = d->out_col_stride; g.out_b1 = d->out_b1_stride; g.out_b2 = d->out_b2_stride;
@@ -745,31 +799,56 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   g.in_split = d->in_split; g.in_nfloor = d->in_split_nfloor;
   g.out_split = d->out_split; g.out_nfloor = d->out_split_nfloor;
   g.n = d->n; g.ncols = d->ncols; g.nb1 = d->nb1;
+  g.in_contig = d->in_contig; g.out_contig = d->out_contig;
   g.conj = d->direction > 0;
   g.real_in = d->real_input;
   g.scale = d->scale;
-  long long nblk = (long long)d->ncols * d->nb1 * d->nb2;
+  // radices: prime factors, pairs of 2 merged into 4 (fewer LDS round trips at equal cost)
+  g.nfac = 0;
+  {
+    int m = d->n, twos = 0;
+    while (m % 2 == 0) { twos++; m /= 2; }
+    for (; twos >= 2; twos -= 2) g.fac[g.nfac++] = 4;
+    if (twos) g.fac[g.nfac++] = 2;
+    for (int f = 3; f * f <= m; f += 2)
+      while (m % f == 0) {
+        if (g.nfac >= OFFT_MIX_MAXFAC) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: n=%d has too many factors", d->n); return -1; }
+        g.fac[g.nfac++] = f; m /= f;
+      }
+    if (m > 1) g.fac[g.nfac++] = m;
+    if (d->n == 1) { g.nfac = 0; }
+    if (g.nfac > OFFT_MIX_MAXFAC) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: n=%d has too many factors", d->n); return -1; }
+  }
+  const size_t esz = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  const size_t lds_cap = 160 * 1024;
+  if (2 * (size_t)d->n * esz > lds_cap) {
+    snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: n=%d too long for the any-length kernel", d->n);
+    return -1;
+  }
+  int cols = 8;
+  while (cols > 1 && (2 * (size_t)cols + 1) * d->n * esz > lds_cap) cols >>= 1;
+  g.tw_in_lds = (2 * (size_t)cols + 1) * d->n * esz <= lds_cap;
+  g.cols = cols;
+  g.ncp = (d->ncols + cols - 1) / cols;
+  size_t lds = (2 * (size_t)cols + (g.tw_in_lds ? 1 : 0)) * d->n * esz;
+  long long nblk = (long long)g.ncp * d->nb1 * d->nb2;
   if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
-  size_t esz = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
-  size_t lds = (size_t)d->n * esz;
-  if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: n=%d too long for the generic kernel", d->n); return -1; }
-  int threads = d->n >= 256 ? 256 : (d->n > 64 ? 128 : 64);
   (void)hipGetLastError();  // start from a clean slate: the check below must see only this launch
   if (d->precision == OFFT_PREC_F64) {
     static bool set64 = false;
     if (lds > 48 * 1024 && !set64) {
-      HIPK_CHECK(hipFuncSetAttribute((const void *)dft_generic_k<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPK_CHECK(hipFuncSetAttribute((const void *)fft_mixed_k<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
       set64 = true;
     }
-    hipLaunchKernelGGL(dft_generic_k<double>, dim3((unsigned)nblk), dim3(threads), lds, st, g, (const double2 *)in,
+    hipLaunchKernelGGL(fft_mixed_k<double>, dim3((unsigned)nblk), dim3(256), lds, st, g, (const double2 *)in,
                        (double2 *)out, (const double2 *)tb.full);
   } else {
     static bool set32 = false;
     if (lds > 48 * 1024 && !set32) {
-      HIPK_CHECK(hipFuncSetAttribute((const void *)dft_generic_k<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPK_CHECK(hipFuncSetAttribute((const void *)fft_mixed_k<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
       set32 = true;
     }
-    hipLaunchKernelGGL(dft_generic_k<float>, dim3((unsigned)nblk), dim3(threads), lds, st, g, (const float2 *)in,
+    hipLaunchKernelGGL(fft_mixed_k<float>, dim3((unsigned)nblk), dim3(256), lds, st, g, (const float2 *)in,
                        (float2 *)out, (const float2 *)tb.full);
   }
   HIPK_CHECK(hipGetLastError());

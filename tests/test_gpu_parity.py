@@ -70,9 +70,11 @@ def test_non_cubic_pow2(built, shape):
         check64(got, want)
 
 
-@pytest.mark.parametrize("shape", [(20, 20, 20), (18, 12, 30), (7, 5, 3), (1, 9, 1), (1, 1, 1), (100, 3, 6), (3, 96, 50)])
+@pytest.mark.parametrize("shape", [(20, 20, 20), (18, 12, 30), (7, 5, 3), (1, 9, 1), (1, 1, 1), (100, 3, 6), (3, 96, 50),
+                                   (120, 96, 100), (127, 6, 4), (4, 1000, 8), (2, 2, 4093), (384, 4, 4), (6, 5000, 2)])
 def test_any_length_generic_kernel(built, shape):
-    """lengths without a Stockham fast path (FFTW accepts any N): generic kernel, same tolerance"""
+    """lengths without a register fast path (FFTW accepts any N): mixed-radix any-length kernel (composite,
+    prime, large prime 4093, > 4096), same tolerance"""
     for layout in (dict(S=1), dict()):
         got, _ = gpu_fft(shape, **layout)
         want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)

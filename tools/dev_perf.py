@@ -44,12 +44,6 @@ if __name__ == "__main__":
             print("OFFT_WPAD", pad)
             run(N, 0, 0)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[2] == "zchunk":
-        for ch in (0, 1, 2, 4, 8, 16, 32):
-            os.environ["OFFT_ZCHUNK"] = str(ch)
-            print("OFFT_ZCHUNK", ch)
-            run(N, 0, 0)
-        sys.exit(0)
     for S, eq in ((1, 0), (0, 0), (0, 1)):
         run(N, S, eq)
     nv = api.lib().offt_hipk_variant_count(N, 0)
