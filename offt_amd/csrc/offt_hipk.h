@@ -60,6 +60,9 @@ int offt_hipk_has_fast_path(int n, int precision);
 int offt_hipk_variant_count(int n, int precision);
 /* human-readable description of a variant, for sweep logs                      */
 const char *offt_hipk_variant_name(int n, int precision, int variant);
+/* panel shape of a variant (variant = -1: the default): elements per thread and columns
+ * per workgroup; returns the variant id or -1 if (n, precision, variant) does not exist  */
+int offt_hipk_variant_info(int n, int precision, int variant, int *elems_per_thread, int *cols);
 /* name of the kernel symbol a descriptor resolves to (for rocprof matching)    */
 const char *offt_hipk_kernel_name(const offt_pass_desc *d);
 /* strided complex copy / permutation (used for layouts no FFT pass can fold)   */

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "offt_hip.h"
 #include "offt_hipk.h"
@@ -68,6 +69,8 @@ typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[OFFT_HIP_UNIQUE_ID_BYTES]; } ncclUniqueId;
 typedef int ncclResult_t;
 #define NCCL_INT8 0
+#define NCCL_FLOAT64 8
+#define NCCL_MAX 2
 static struct {
   void *lib;
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -76,6 +79,7 @@ static struct {
   ncclResult_t (*CommDestroy)(ncclComm_t);
   ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
   ncclResult_t (*GroupStart)(void);
   ncclResult_t (*GroupEnd)(void);
   const char *(*GetErrorString)(ncclResult_t);
@@ -98,6 +102,7 @@ static int rccl_load(void) {
   RSYM(CommDestroy, "ncclCommDestroy");
   RSYM(Send, "ncclSend");
   RSYM(Recv, "ncclRecv");
+  RSYM(AllReduce, "ncclAllReduce");
   RSYM(GroupStart, "ncclGroupStart");
   RSYM(GroupEnd, "ncclGroupEnd");
   RSYM(GetErrorString, "ncclGetErrorString");
@@ -119,6 +124,9 @@ static struct {
   int rank, size, device, have_comm;
   ncclComm_t world;
 } G = {0, 1, 0, 0, NULL};
+
+static int is_device_ptr(const void *p);
+static void static_sweep(struct _offt_plan *po, void *user_buf);
 
 /* test-only backend override, see offt_backend.h */
 static const offt_backend *g_backend = NULL;
@@ -426,10 +434,12 @@ static void desc_init(offt_pass_desc *d, const hip_state *st, int n, int dir, in
 /* ------------------------------------------------------------------------- */
 /* plan                                                                       */
 /* ------------------------------------------------------------------------- */
-static void state_free(hip_state *st) {
-  if (!st) return;
+/* ------------------------------------------------------------------------- */
+/* tile ring: (W1+1) send/receive pairs of T1 x-planes (set_buffer,            */
+/* offt-compute.c:710-746).  Rebuilt when the static sweep tries another T1/W1.*/
+/* ------------------------------------------------------------------------- */
+static void ring_teardown(hip_state *st) {
   const offt_backend *be = st->be;
-  be->dfree(st->work);
   for (int r = 0; r < st->ring; r++) {
     if (st->send1) be->dfree(st->send1[r]);
     if (st->recv1 && st->recv1 != st->send1) be->dfree(st->recv1[r]);
@@ -440,6 +450,41 @@ static void state_free(hip_state *st) {
   if (st->recv1 != st->send1) free(st->recv1);
   free(st->send1);
   free(st->ev_k1); free(st->ev_a1); free(st->ev_k2);
+  st->send1 = st->recv1 = NULL; st->ev_k1 = st->ev_a1 = st->ev_k2 = NULL;
+  st->ring = 0;
+}
+
+static int ring_setup(struct _offt_plan *po, hip_state *st) {
+  const offt_backend *be = st->be;
+  const struct _offt_comm *c = po->comm;
+  st->T = po->params->v[_T1_];
+  if (st->T < 1) st->T = 1;
+  if (st->T > c->M1) st->T = c->M1;
+  st->ntiles = (c->M1 + st->T - 1) / st->T;
+  int W = po->params->v[_W1_];
+  if (W < 0) W = 0;
+  st->ring = W + 1;
+  if (st->ring > st->ntiles) st->ring = st->ntiles;
+  st->blk1 = (size_t)st->T * c->M2 * c->M3;
+  st->send1 = (void **)calloc(st->ring, sizeof(void *));
+  st->recv1 = st->x1 ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
+  st->ev_k1 = (void **)calloc(st->ring, sizeof(void *));
+  st->ev_a1 = (void **)calloc(st->ring, sizeof(void *));
+  st->ev_k2 = (void **)calloc(st->ring, sizeof(void *));
+  for (int r = 0; r < st->ring; r++) {
+    st->send1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
+    if (st->x1) st->recv1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
+    st->ev_k1[r] = be->event_create(); st->ev_a1[r] = be->event_create(); st->ev_k2[r] = be->event_create();
+    if (!st->send1[r] || !st->recv1[r]) return -1;
+  }
+  return 0;
+}
+
+static void state_free(hip_state *st) {
+  if (!st) return;
+  const offt_backend *be = st->be;
+  be->dfree(st->work);
+  ring_teardown(st);
   if (st->send2 != st->recv2) be->dfree(st->send2);
   be->dfree(st->recv2);
   be->dfree(st->stage);
@@ -472,7 +517,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   params_default(po);
   if (!po->rank) print_params(po->params->v); /* offt-compute.c:3416 */
   if (max_loop > 0 && !po->rank)
-    printf("offt(hip): Active-Harmony tuning (max_loop=%d) is replaced by the static kernel sweep; using default/custom parameters\n", max_loop);
+    printf("offt(hip): max_loop=%d: Active-Harmony search replaced by a static sweep of at most %d points\n", max_loop, max_loop);
   params_custom(po, custom_params);
   {
     int p1 = po->params->v[_P1_];
@@ -504,6 +549,20 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
       goto fail;
     }
   }
+  /* a caller-supplied point (run-fft -P <E> -p <cols>, or a line of the sweep's point database)
+   * selects the panel kernel whose shape it names; anything else keeps the registry default */
+  if (custom_params && custom_params->v[_Px1_] > 0 && custom_params->v[_Py1_] > 0 && !g_backend) {
+    const int dims[3] = {Nx, Ny, Nz};
+    for (int ax = 0; ax < 3; ax++) {
+      const int nv = offt_hipk_variant_count(dims[ax], precision);
+      for (int var = 0; var < nv; var++) {
+        int e = 0, cols = 0;
+        if (offt_hipk_variant_info(dims[ax], precision, var, &e, &cols) == var && e == custom_params->v[_Px1_] &&
+            cols == custom_params->v[_Py1_])
+          st->variant[ax] = var;
+      }
+    }
+  }
   st->use_pipeline = (po->p > 1) || (getenv("OFFT_FORCE_PIPELINE") && atoi(getenv("OFFT_FORCE_PIPELINE")));
   if (be->prepare(Nx, precision) || be->prepare(Ny, precision) || be->prepare(Nz, precision)) {
     if (!g_backend) SET_ERR("twiddle setup failed: %s", offt_hipk_last_error());
@@ -525,29 +584,11 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     const int force = getenv("OFFT_FORCE_A2A") && atoi(getenv("OFFT_FORCE_A2A"));
     st->x1 = (p2 > 1) || force;
     st->x2 = (p1 > 1) || force;
-    st->T = po->params->v[_T1_];
-    if (st->T > c->M1) st->T = c->M1;
     st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
                    !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
     if (st->slab_zyx) st->x2 = 0; /* p1 == 1: there is no second exchange, K2 stores K3's input directly */
-    st->ntiles = (c->M1 + st->T - 1) / st->T;
-    int W = po->params->v[_W1_];
-    if (W < 0) W = 0;
-    st->ring = W + 1;
-    if (st->ring > st->ntiles) st->ring = st->ntiles;
-    st->blk1 = (size_t)st->T * c->M2 * c->M3;
     st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
-    st->send1 = (void **)calloc(st->ring, sizeof(void *));
-    st->recv1 = st->x1 ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
-    st->ev_k1 = (void **)calloc(st->ring, sizeof(void *));
-    st->ev_a1 = (void **)calloc(st->ring, sizeof(void *));
-    st->ev_k2 = (void **)calloc(st->ring, sizeof(void *));
-    for (int r = 0; r < st->ring; r++) {
-      st->send1[r] = be->dmalloc(st->blk1 * p2 * st->esz);
-      if (st->x1) st->recv1[r] = be->dmalloc(st->blk1 * p2 * st->esz);
-      st->ev_k1[r] = be->event_create(); st->ev_a1[r] = be->event_create(); st->ev_k2[r] = be->event_create();
-      if (!st->send1[r] || !st->recv1[r]) goto fail;
-    }
+    if (ring_setup(po, st)) goto fail;
     st->recv2 = be->dmalloc(st->blk2 * p1 * st->esz);
     st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
     if (!st->recv2 || !st->send2) goto fail;
@@ -572,6 +613,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     }
   }
   po->t_init[INIT_BUFFER] = wall_seconds() - tb0;
+  if (max_loop > 0 && !g_backend) static_sweep(po, out);
   po->t_init[INIT_ALL] = wall_seconds() - t0;
   if (!po->rank) /* offt-compute.c:3469-3471 */
     printf("M1 %d M2 %d M3 %d M4 %d m1 %d m2 %d m3 %d m4 %d\n", c->M1, c->M2, c->M3, c->M4, c->m1, c->m2, c->m3, c->m4);
@@ -580,6 +622,137 @@ fail:
   state_free(st);
   free(po->comm); free(po->params); free(po);
   return NULL;
+}
+
+/* ------------------------------------------------------------------------- */
+/* static sweep: what replaces ah_tuning() (offt-tuning.c:744-1023).          */
+/*                                                                           */
+/* offt_3d_init(..., max_loop > 0, ...) in the reference starts an Active-    */
+/* Harmony search over the 24-D lattice, timing offt_3d_execute(is_tuning=1)  */
+/* per point and logging "perf v0 .. v23" lines to a point database           */
+/* (offt-tuning.c:231-277).  Here the search space is the handful of knobs    */
+/* that matter on the GPU and it is enumerated, not searched:                 */
+/*   single rank : LDS panel shape / radix order = kernel variant, recorded   */
+/*                 in the point as Px1 = elements per thread, Py1 = columns   */
+/*   p1 x p2     : tile thickness T1 in {T/2, T, 2T} x window W1 in {1, 2, 3} */
+/* at most max_loop points, each timed like the tuner does (one warm-up, then */
+/* TUNING_REPS executes, device time, max over ranks).  Points are appended   */
+/* to the same text format, and a point already in the file is not re-timed   */
+/* (is_in_database_point, offt-tuning.c:231-263).                             */
+/* ------------------------------------------------------------------------- */
+static int db_lookup(const char *path, const int *v, double *perf) {
+  FILE *f = fopen(path, "r");
+  if (!f) return 0;
+  double pr;
+  int y[PARAM_COUNT], found = 0;
+  while (fscanf(f, "%lf", &pr) == 1) {
+    int ok = 1;
+    for (int j = 0; j < PARAM_COUNT; j++) {
+      if (fscanf(f, "%d", &y[j]) != 1) { ok = 0; break; }
+      if (y[j] != v[j]) ok = 0;
+    }
+    if (ok) { *perf = pr; found = 1; break; }
+  }
+  fclose(f);
+  return found;
+}
+
+static void db_append(const char *path, const int *v, double perf) {
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  fprintf(f, "%.5f ", perf);
+  for (int j = 0; j < PARAM_COUNT; j++) fprintf(f, "%d ", v[j]);
+  fprintf(f, "\n");
+  fclose(f);
+}
+
+static double sweep_time_point(struct _offt_plan *po, void *buf) {
+  hip_state *st = (hip_state *)po->hip_state;
+  double best = 1e30;
+  offt_3d_execute_dir(po, buf, buf, -1); /* warm-up */
+  if (po->t[ALL] >= 99999999.0) return 99999999.0;
+  for (int r = 0; r < TUNING_REPS; r++) {
+    offt_3d_execute_dir(po, buf, buf, -1);
+    if (po->t[ALL] >= 99999999.0) return 99999999.0;
+    if (st->last_dev_s < best) best = st->last_dev_s;
+  }
+  if (po->p > 1 && G.have_comm) { /* every rank must rank the points identically: max over ranks */
+    double *d = (double *)st->be->dmalloc(sizeof(double));
+    if (!d) return 99999999.0;
+    if (hipMemcpy(d, &best, sizeof best, hipMemcpyHostToDevice) != hipSuccess ||
+        R.AllReduce(d, d, 1, NCCL_FLOAT64, NCCL_MAX, G.world, (hipStream_t)st->s_compute) != 0 ||
+        hipStreamSynchronize((hipStream_t)st->s_compute) != hipSuccess ||
+        hipMemcpy(&best, d, sizeof best, hipMemcpyDeviceToHost) != hipSuccess)
+      best = 99999999.0;
+    st->be->dfree(d);
+  }
+  return best;
+}
+
+static void static_sweep(struct _offt_plan *po, void *user_buf) {
+  hip_state *st = (hip_state *)po->hip_state;
+  int *v = po->params->v;
+  const double t0 = wall_seconds();
+  const char *envdb = getenv("OFFT_SWEEP_DB");
+  if (envdb) snprintf(po->point_database_file, sizeof po->point_database_file, "%s", envdb);
+  else snprintf(po->point_database_file, sizeof po->point_database_file, "./tmp-db-%08d", (int)(getpid() % 100000000));
+  if (!po->rank) printf("point_database_file %s\n", po->point_database_file);
+  void *buf = user_buf;
+  int own = 0;
+  if (!buf || !is_device_ptr(buf)) { /* tune on scratch: never stage a host array per point */
+    buf = st->be->dmalloc(local_elems(po->comm) * st->esz);
+    own = 1;
+    if (!buf) return;
+    (void)hipMemset(buf, 0, local_elems(po->comm) * st->esz);
+  }
+  int best_v[PARAM_COUNT], points = 0, best_variant = -1;
+  double best = 1e30;
+  memcpy(best_v, v, sizeof best_v);
+  if (!st->use_pipeline) {
+    int nv = offt_hipk_variant_count(po->Nx, st->prec);
+    const int ny = offt_hipk_variant_count(po->Ny, st->prec), nz = offt_hipk_variant_count(po->Nz, st->prec);
+    if (ny > nv) nv = ny;
+    if (nz > nv) nv = nz;
+    for (int var = 0; var < nv && points < po->max_loop; var++, points++) {
+      int e = 0, cols = 0;
+      if (offt_hipk_variant_info(po->Nx, st->prec, var, &e, &cols) < 0 &&
+          offt_hipk_variant_info(po->Ny, st->prec, var, &e, &cols) < 0 &&
+          offt_hipk_variant_info(po->Nz, st->prec, var, &e, &cols) < 0)
+        continue;
+      v[_Px1_] = e; v[_Py1_] = cols;
+      for (int ax = 0; ax < 3; ax++) st->variant[ax] = var;
+      double perf;
+      if (po->rank || !db_lookup(po->point_database_file, v, &perf)) {
+        perf = sweep_time_point(po, buf);
+        if (!po->rank) db_append(po->point_database_file, v, perf);
+      }
+      if (!po->rank) { printf("@ SWEEP %.5f ", perf); print_params(v); }
+      if (perf < best) { best = perf; best_variant = var; memcpy(best_v, v, sizeof best_v); }
+    }
+    for (int ax = 0; ax < 3; ax++) st->variant[ax] = best_variant;
+  } else {
+    const int T0 = v[_T1_];
+    const int Tc[3] = {T0 / 2 > 0 ? T0 / 2 : 1, T0, 2 * T0 <= po->comm->M1 ? 2 * T0 : po->comm->M1};
+    const int Wc[3] = {1, 2, 3};
+    for (int ti = 0; ti < 3 && points < po->max_loop; ti++) {
+      if (ti > 0 && Tc[ti] == Tc[ti - 1]) continue;
+      for (int wi = 0; wi < 3 && points < po->max_loop; wi++, points++) {
+        v[_T1_] = Tc[ti]; v[_W1_] = Wc[wi];
+        ring_teardown(st);
+        if (ring_setup(po, st)) { v[_T1_] = best_v[_T1_]; v[_W1_] = best_v[_W1_]; continue; }
+        double perf = sweep_time_point(po, buf);
+        if (!po->rank) { db_append(po->point_database_file, v, perf); printf("@ SWEEP %.5f ", perf); print_params(v); }
+        if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
+      }
+    }
+    memcpy(v, best_v, sizeof best_v);
+    ring_teardown(st);
+    (void)ring_setup(po, st);
+  }
+  memcpy(v, best_v, sizeof best_v);
+  po->params->is_converged = 1;
+  if (own) st->be->dfree(buf);
+  po->t_init[INIT_AH] = wall_seconds() - t0;
 }
 
 struct _offt_plan *offt_3d_init(int Nx, int Ny, int Nz, double *in, double *out, int is_r2c, int fftw_flag,

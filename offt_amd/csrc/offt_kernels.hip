@@ -560,7 +560,7 @@ struct Variant {
   int id;
   bool is_default;  // default for this (n, prec, inc, outc) flavour
   bool r2c;         // real-input z-pass instantiation
-  int cols, threads;
+  int cols, threads, e;
   size_t lds;
   const void *fn;
   std::string name;
@@ -584,7 +584,7 @@ void reg_variant(int id, int defmask = -1) {
   snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
            R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
   auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
-    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::LDS_BYTES, fn, nm, false});
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false});
   };
   add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
   add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
@@ -745,6 +745,14 @@ int offt_hipk_variant_count(int n, int precision) {
 const char *offt_hipk_variant_name(int n, int precision, int variant) {
   Variant *v = find_variant(n, precision, true, true, variant);
   return v ? v->name.c_str() : "mixed-radix any-length";
+}
+
+int offt_hipk_variant_info(int n, int precision, int variant, int *elems_per_thread, int *cols) {
+  Variant *v = find_variant(n, precision, true, true, variant);
+  if (!v || (variant >= 0 && v->id != variant)) return -1;
+  if (elems_per_thread) *elems_per_thread = v->e;
+  if (cols) *cols = v->cols;
+  return v->id;
 }
 
 const char *offt_hipk_kernel_name(const offt_pass_desc *d) {

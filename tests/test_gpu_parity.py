@@ -248,3 +248,40 @@ def test_r2c_forced_pipeline(built, monkeypatch):
         got, _ = gpu_fft(shape, is_r2c=1, **kw)
         want, _, _ = O.world_fft(*shape, 1, kind=1, is_r2c=1, **kw)
         check64(got, want)
+
+
+def test_harness_and_static_sweep(built, tmp_path):
+    """bin/run-fft (run-fft.c counterpart): reference stdout lines, closed-form spot values, and -l N = the
+    static sweep that replaces the Active-Harmony tuner, logging the reference's "perf v0..v23" point lines"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "run-fft")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", root, "harness"])
+    db = tmp_path / "points.db"
+    env = dict(os.environ, OFFT_SWEEP_DB=str(db))
+    n = 512
+    out = subprocess.check_output([exe, "-N", str(n), "-n", str(n), "-L", str(n), "-r", "2", "-v", "-g", "-l", "4"],
+                                  env=env, stderr=subprocess.STDOUT).decode()
+    lines = out.splitlines()
+    assert any(l.startswith("@ INPUT") for l in lines) and any(l.startswith("@ FINAL") for l in lines)
+    assert any(l.startswith("t_init ") for l in lines) and any(l.startswith("t_min ") for l in lines)
+    sweep = [l for l in lines if l.startswith("@ SWEEP")]
+    assert len(sweep) >= 2, out
+    spots = [l for l in lines if l.startswith("p 0: 0 0 ")]
+    assert len(spots) == 4
+    x0 = float(spots[0].split(":")[2].split()[0])
+    assert x0 == n ** 3 * 111 * (n - 1) / 2
+    for k in (1, 2, 3):
+        re, im = map(float, spots[k].split(":")[2].split())
+        cf = n ** 3 * (-0.5 + 0.5j / np.tan(np.pi * k / n))
+        assert abs(complex(re, im) - cf) / abs(cf) < 1e-9  # printed with 5 decimals
+    pts = [l.split() for l in open(db).read().splitlines()]
+    assert len(pts) == len(sweep) and all(len(p) == 25 for p in pts)  # perf + 24 parameters
+    final = [l for l in lines if l.startswith("@ FINAL")][0].split()
+    best = min(pts, key=lambda p: float(p[0]))
+    assert int(final[final.index("Px1") + 1]) == int(best[1 + 3]) and int(final[final.index("Py1") + 1]) == int(best[1 + 4])
+    # second run: every point is already in the database and is not re-timed
+    out2 = subprocess.check_output([exe, "-N", str(n), "-n", str(n), "-L", str(n), "-l", "4"], env=env,
+                                   stderr=subprocess.STDOUT).decode()
+    assert len(open(db).read().splitlines()) == len(pts), out2
