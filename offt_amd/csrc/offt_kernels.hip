@@ -181,7 +181,8 @@ struct PanelCfg {
   // register budget: an E-point thread keeps E*sizeof(T)/2 data VGPRs; it needs
   // roughly twice that (butterfly temporaries, addresses, exchange staging)
   static constexpr int DATA_VGPR = E * (int)sizeof(T) / 2;
-  static constexpr int WPS_REG = DATA_VGPR >= 128 ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
+  // (a radix-32 butterfly alone keeps ~40 temporaries alive: never ask for more than 2 waves/SIMD)
+  static constexpr int WPS_REG = (DATA_VGPR >= 128 || R0 >= 32 || R1 >= 32 || R2 >= 32) ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
   static constexpr int WPS_MIN = (NT + 255) / 256;  // one workgroup must fit on a CU
   static constexpr int WPS_E = WPS < WPS_REG ? WPS : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
 };
@@ -602,6 +603,14 @@ void build_registry() {
 #ifdef OFFT_DEV_ONLY_1024  /* developer switch: compile just the 1024 kernels for quick iteration */
   reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
   reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
+#ifdef OFFT_DEV_EXTRA
+  reg_variant<double, 1024, 16, 4, 16, 16, 8, true>(2, 0);
+  reg_variant<double, 1024, 16, 16, 4, 16, 8, true>(3, 0);
+  reg_variant<double, 1024, 16, 16, 16, 4, 16, true>(4, 0);
+  reg_variant<double, 1024, 16, 16, 16, 4, 4, true>(5, 0);
+  reg_variant<double, 1024, 16, 16, 16, 4, 8, false>(6, 0);
+  reg_variant<double, 1024, 32, 32, 32, 1, 16, true>(7, 0);
+#endif
 #else
   // ---- f64 ----
   reg_variant<double, 2, 2, 2, 1, 1, 64, false>(0);
