@@ -603,6 +603,12 @@ void build_registry() {
 #ifdef OFFT_DEV_ONLY_1024  /* developer switch: compile just the 1024 kernels for quick iteration */
   reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
   reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
+#ifdef OFFT_DEV_F32
+  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
+  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, 0);
+  reg_variant<float, 2048, 32, 16, 16, 8, 8, true>(2, 0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(3, 0);
+#endif
 #ifdef OFFT_DEV_EXTRA
   reg_variant<double, 1024, 16, 4, 16, 16, 8, true>(2, 0);
   reg_variant<double, 1024, 16, 16, 4, 16, 8, true>(3, 0);

@@ -181,3 +181,12 @@ def test_gloo_world4(built, tmp_path):
              dict(N=[8, 8, 8], params=dict(P1=1, T1=3)), dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1)),
              dict(N=[6, 10, 7], params=dict(P1=2, S=1))]
     _run_world(4, cases, tmp_path)
+
+
+def test_gloo_world8(built, tmp_path):
+    """the 8-rank shapes the multi-GPU bench uses (1x8 slab, 2x4 pencil, 8x1), incl. r2c and ragged sizes"""
+    cases = [dict(N=[16, 16, 16], params=dict(P1=1)), dict(N=[16, 16, 16], params=dict()),
+             dict(N=[16, 16, 16], params=dict(P1=8)), dict(N=[16, 16, 16], params=dict(P1=1, S=1, T1=4)),
+             dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[16, 16, 16], params=dict(P1=1), r2c=1),
+             dict(N=[16, 16, 16], params=dict(P1=4), eq=1)]
+    _run_world(8, cases, tmp_path)

@@ -34,6 +34,14 @@ def run(N, S, eq, variants=(-1, -1, -1), prec=api.F64, reps=4):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    if len(sys.argv) > 2 and sys.argv[2] == "f32":
+        run(N, 0, 0, prec=api.F32, reps=3)
+        run(N, 1, 0, prec=api.F32, reps=3)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "f64":
+        run(N, 0, 0, reps=3)
+        run(N, 1, 0, reps=3)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "zyx":
         for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
             run(N, 0, 0, reps=6)
