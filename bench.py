@@ -144,9 +144,11 @@ def main():
             kname = f"fft_panel_k ({names[k]}-axis pass)"
             alg_launch = 2.0 * 16.0 * E
         else:
-            k = 2
-            kdur = pass_acc[2] / steps
-            kname = "fft_panel_k (x-axis pass, K3)"
+            # multi-rank slab schedule: phase 0 = the FFTz launches (K1, all x-tiles, no waiting on the
+            # exchange); phase 2 = z-chunks of exchange-wait + FFTy + FFTx, which includes time on the wire
+            k = 0
+            kdur = pass_acc[0] / steps
+            kname = "fft_panel_k (z-axis pass K1, all x-tiles)"
             alg_launch = 2.0 * 16.0 * E / world
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -127,6 +127,9 @@ static struct {
 
 static int is_device_ptr(const void *p);
 static void static_sweep(struct _offt_plan *po, void *user_buf);
+struct hip_state;
+static void slab_teardown(struct hip_state *st);
+static int slab_setup(struct _offt_plan *po, struct hip_state *st);
 
 /* test-only backend override, see offt_backend.h */
 static const offt_backend *g_backend = NULL;
@@ -322,7 +325,13 @@ typedef struct hip_state {
   void *work; size_t work_elems; /* single path: transposed-output scratch */
   /* pipeline */
   int T, ntiles, ring;
-  int slab_zyx;          /* p1 == 1 and z-y-x output: x-contiguous exchange layout, see execute_pipeline */
+  int slab_zyx;          /* p1 == 1 and z-y-x output: single-exchange slab schedule, see execute_slab() */
+  int t1_custom, t2_custom; /* the caller fixed T1 / T2 (run-fft -T / -t): use them as given */
+  int sT, sTz, sNt, sH;  /* slab schedule: x-tile, z-chunk thickness, #tiles, #chunks */
+  size_t sblkS, sblkR;   /* elements per (tile, peer) block in S1 / in a chunk buffer */
+  void *S1, *R1[2], *R2; /* packed send volume, double-buffered chunk receive, y-transformed volume */
+  void **ev_s1;          /* per x-tile: K1 done */
+  void *ev_sa[2], *ev_sc[2]; /* per chunk slot: all messages arrived / chunk consumed */
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   void **send1, **recv1; /* ring */
@@ -485,6 +494,7 @@ static void state_free(hip_state *st) {
   const offt_backend *be = st->be;
   be->dfree(st->work);
   ring_teardown(st);
+  slab_teardown(st);
   if (st->send2 != st->recv2) be->dfree(st->send2);
   be->dfree(st->recv2);
   be->dfree(st->stage);
@@ -586,12 +596,18 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     st->x2 = (p1 > 1) || force;
     st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
                    !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
-    if (st->slab_zyx) st->x2 = 0; /* p1 == 1: there is no second exchange, K2 stores K3's input directly */
+    st->t1_custom = custom_params && custom_params->v[_T1_] >= 0;
+    st->t2_custom = custom_params && custom_params->v[_T2_] >= 0;
     st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
-    if (ring_setup(po, st)) goto fail;
-    st->recv2 = be->dmalloc(st->blk2 * p1 * st->esz);
-    st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
-    if (!st->recv2 || !st->send2) goto fail;
+    if (st->slab_zyx) {
+      st->x2 = 0; /* p1 == 1: there is no second exchange */
+      if (slab_setup(po, st)) goto fail;
+    } else if (ring_setup(po, st)) goto fail;
+    if (!st->slab_zyx) {
+      st->recv2 = be->dmalloc(st->blk2 * p1 * st->esz);
+      st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
+      if (!st->recv2 || !st->send2) goto fail;
+    }
     st->ev_a2_last = be->event_create(); st->ev_k3 = be->event_create();
     st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create(); st->s_k1 = be->stream_create();
     if (!g_backend && (po->p > 1 || force)) {
@@ -730,6 +746,31 @@ static void static_sweep(struct _offt_plan *po, void *user_buf) {
       if (perf < best) { best = perf; best_variant = var; memcpy(best_v, v, sizeof best_v); }
     }
     for (int ax = 0; ax < 3; ax++) st->variant[ax] = best_variant;
+  } else if (st->slab_zyx) {
+    /* slab schedule: x-tile thickness T1 (message granularity of the exchange) x z-chunk
+     * thickness T2 (granularity of the overlapped FFTy/FFTx work) around the merged defaults */
+    const int T0 = st->sT, Z0 = st->sTz, M1 = po->comm->M1, M3 = po->comm->M3;
+    const int Tc[3] = {T0 / 2 > 0 ? T0 / 2 : 1, T0, 2 * T0 <= M1 ? 2 * T0 : M1};
+    const int Zc[3] = {Z0 / 2 > 0 ? Z0 / 2 : 1, Z0, 2 * Z0 <= M3 ? 2 * Z0 : M3};
+    st->t1_custom = st->t2_custom = 1;
+    v[_T1_] = T0; v[_T2_] = Z0;
+    memcpy(best_v, v, sizeof best_v);
+    for (int ti = 0; ti < 3 && points < po->max_loop; ti++) {
+      if (ti > 0 && Tc[ti] == Tc[ti - 1]) continue;
+      for (int zi = 0; zi < 3 && points < po->max_loop; zi++) {
+        if (zi > 0 && Zc[zi] == Zc[zi - 1]) continue;
+        v[_T1_] = Tc[ti]; v[_T2_] = Zc[zi];
+        slab_teardown(st);
+        if (slab_setup(po, st)) continue;
+        double perf = sweep_time_point(po, buf);
+        points++;
+        if (!po->rank) { db_append(po->point_database_file, v, perf); printf("@ SWEEP %.5f ", perf); print_params(v); }
+        if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
+      }
+    }
+    memcpy(v, best_v, sizeof best_v);
+    slab_teardown(st);
+    (void)slab_setup(po, st);
   } else {
     const int T0 = v[_T1_];
     const int Tc[3] = {T0 / 2 > 0 ? T0 / 2 : 1, T0, 2 * T0 <= po->comm->M1 ? 2 * T0 : po->comm->M1};
@@ -921,6 +962,156 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* slab schedule (p1 == 1, z-y-x output): ONE exchange, streamed in z-chunks   */
+/*                                                                           */
+/* With p1 == 1 every rank holds all x and all z of its y-block, there is no  */
+/* second exchange, and the reference's phase 2 (z-tiles of T2 planes:        */
+/* unpack2 + FFTx, offt-compute.c:3682-3862) only needs the planes it works   */
+/* on.  So the exchange is ordered z-chunk-major:                            */
+/*   K1(i)     FFTz of x-tile i, stored per peer as [z_l][y][x_t]   (all i)   */
+/*   a2a(h,i)  z-chunk h of tile i to every peer  (comm stream, back to back) */
+/*   K2(h)     FFTy of chunk h from the receive slot into R2[z_l][y][x]       */
+/*   K3(h)     FFTx of chunk h, contiguous lines, into the caller's z-y-x     */
+/* K2(h)/K3(h) run while chunk h+1 is on the wire; only the last chunk's      */
+/* compute is exposed, instead of a whole x pass after the last tile.  Three  */
+/* HBM round trips, every kernel reads or writes whole lines or 128-B runs.   */
+/* T1 / T2 keep their reference meaning (x-tile thickness of the exchange,    */
+/* z-thickness of the phase-2 work); unless the caller fixed them they are    */
+/* merged upwards until a per-peer message is at least 4 MiB -- the           */
+/* reference defaults (M/16) were sized for CPU caches and MPI eager limits.  */
+/* ------------------------------------------------------------------------- */
+static void slab_teardown(hip_state *st) {
+  const offt_backend *be = st->be;
+  be->dfree(st->S1); be->dfree(st->R1[0]); be->dfree(st->R1[1]); be->dfree(st->R2);
+  st->S1 = st->R1[0] = st->R1[1] = st->R2 = NULL;
+  for (int i = 0; i < st->sNt && st->ev_s1; i++) be->event_destroy(st->ev_s1[i]);
+  free(st->ev_s1); st->ev_s1 = NULL;
+  for (int k = 0; k < 2; k++) {
+    be->event_destroy(st->ev_sa[k]); be->event_destroy(st->ev_sc[k]);
+    st->ev_sa[k] = st->ev_sc[k] = NULL;
+  }
+  st->sNt = 0;
+}
+
+static int slab_setup(struct _offt_plan *po, hip_state *st) {
+  const offt_backend *be = st->be;
+  const struct _offt_comm *c = po->comm;
+  const size_t min_msg = (size_t)(getenv("OFFT_MIN_MSG") ? atol(getenv("OFFT_MIN_MSG")) : 4L << 20);
+  int T = po->params->v[_T1_], Tz = po->params->v[_T2_];
+  if (T < 1) T = 1;
+  if (Tz < 1) Tz = 1;
+  if (!st->t1_custom) { int t4 = (c->M1 + 3) / 4; if (T < t4) T = t4; }
+  if (T > c->M1) T = c->M1;
+  if (!st->t2_custom) {
+    int t8 = (c->M3 + 7) / 8; if (Tz < t8) Tz = t8;
+    while (Tz < c->M3 && (size_t)T * c->M2 * Tz * st->esz < min_msg) Tz *= 2;
+  }
+  if (Tz > c->M3) Tz = c->M3;
+  st->sT = T; st->sTz = Tz;
+  st->sNt = (c->M1 + T - 1) / T;
+  st->sH = (c->M3 + Tz - 1) / Tz;
+  st->sblkS = (size_t)c->M3 * c->M2 * T;
+  st->sblkR = (size_t)Tz * c->M2 * T;
+  st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
+  st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
+  if (!st->S1 || !st->R2) return -1;
+  if (st->x1)
+    for (int k = 0; k < 2; k++) {
+      st->R1[k] = be->dmalloc(st->sblkR * c->p2 * st->sNt * st->esz);
+      if (!st->R1[k]) return -1;
+    }
+  st->ev_s1 = (void **)calloc(st->sNt, sizeof(void *));
+  for (int i = 0; i < st->sNt; i++) st->ev_s1[i] = be->event_create();
+  for (int k = 0; k < 2; k++) { st->ev_sa[k] = be->event_create(); st->ev_sc[k] = be->event_create(); }
+  return 0;
+}
+
+static int execute_slab(struct _offt_plan *po, void *data) {
+  hip_state *st = (hip_state *)po->hip_state;
+  const offt_backend *be = st->be;
+  const struct _offt_comm *c = po->comm;
+  const int p2 = c->p2, T = st->sT, Tz = st->sTz, nt = st->sNt, H = st->sH;
+  const size_t esz = st->esz;
+  void *s = st->s_compute, *sc = st->s_comm1;
+  int peers[p2 > 0 ? p2 : 1];
+  for (int a = 0; a < p2; a++) peers[a] = a;
+  const int nfull = c->m1 / T, tail = c->m1 - nfull * T; /* full x-tiles and the ragged last one */
+
+  /* ---- K1: FFTz + pack (offt-compute.c:905-1206), all x-tiles ---- */
+  be->event_record(st->evp[0], s);
+  for (int i = 0; i < nt; i++) {
+    const int x0 = i * T;
+    int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
+    if (myT > 0 && c->m2 > 0) {
+      offt_pass_desc d;
+      desc_init(&d, st, po->Nz, -1, 2);
+      d.real_input = po->is_r2c;
+      d.ncols = myT; d.nb1 = c->m2;
+      d.in_axis_stride = 1; d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1]; d.in_contig = 1;
+      d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T; d.out_contig = 0;
+      if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
+      if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, (char *)st->S1 + (size_t)i * p2 * st->sblkS * esz, s)) return -1;
+    }
+    be->event_record(st->ev_s1[i], s);
+  }
+  be->event_record(st->evp[1], s);
+
+  for (int h = 0; h < H; h++) {
+    const int slot = h & 1, z0 = h * Tz;
+    int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
+    int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
+    /* ---- a2a(h, i): communicate_a2a (offt-compute.c:862-881), chunk-major ---- */
+    if (st->x1) {
+      if (h >= 2) be->stream_wait(sc, st->ev_sc[slot]); /* receive slot consumed by K2(h-2) */
+      for (int i = 0; i < nt; i++) {
+        if (h == 0) be->stream_wait(sc, st->ev_s1[i]);
+        const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2];
+        for (int a = 0; a < p2; a++) {
+          sp[a] = (char *)st->S1 + (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
+          rp[a] = (char *)st->R1[slot] + ((size_t)i * p2 + a) * st->sblkR * esz;
+          sb[a] = rb[a] = (size_t)tzh * c->M2 * T * esz;
+        }
+        if (be->a2a(st, 1, p2, peers, sp, sb, rp, rb, sc)) return -1;
+      }
+      be->event_record(st->ev_sa[slot], sc);
+      be->stream_wait(s, st->ev_sa[slot]);
+    }
+    /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
+    if (nz > 0) {
+      const char *src = st->x1 ? (const char *)st->R1[slot] : (const char *)st->S1 + (size_t)z0 * c->M2 * T * esz;
+      const size_t blk = st->x1 ? st->sblkR : st->sblkS;
+      for (int part = 0; part < 2; part++) { /* full tiles in one launch, the ragged tile in another */
+        const int ntile = part == 0 ? nfull : (tail > 0 ? 1 : 0);
+        if (!ntile) continue;
+        const int first = part == 0 ? 0 : nfull;
+        offt_pass_desc d;
+        desc_init(&d, st, po->Ny, -1, 1);
+        d.ncols = part == 0 ? T : tail; d.nb1 = nz; d.nb2 = ntile;
+        d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T; d.in_b2_stride = (long long)p2 * blk;
+        if (p2 > 1) { d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0; d.in_block_stride = (long long)blk; }
+        d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
+        if (be->pass(&d, src + (size_t)first * p2 * blk * esz,
+                     (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s)) return -1;
+      }
+    }
+    be->event_record(st->ev_sc[slot], s);
+    /* ---- K3(h): FFTx (offt-compute.c:2729-2730) on whole lines, into the caller's z-y-x layout ---- */
+    if (nz > 0 && c->m4 > 0) {
+      offt_pass_desc d;
+      desc_init(&d, st, po->Nx, -1, 0);
+      d.ncols = c->m4; d.nb1 = nz;
+      d.in_axis_stride = 1; d.in_col_stride = c->M1; d.in_b1_stride = (long long)c->M4 * c->M1; d.in_contig = 1;
+      d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2]; d.out_contig = 1;
+      d.scale = st->out_scale;
+      if (be->pass(&d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s)) return -1;
+    }
+  }
+  be->event_record(st->evp[2], s);
+  be->event_record(st->evp[3], s);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* tile pipeline for p1 x p2 ranks (forward)                                  */
 /*                                                                           */
 /* reference:  for each x-tile i:  FFTz+pack1(i); wait(i-W); ia2a(i);        */
@@ -942,7 +1133,6 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   hip_state *st = (hip_state *)po->hip_state;
   const offt_backend *be = st->be;
   const struct _offt_comm *c = po->comm;
-  if (dir > 0) { SET_ERR("inverse transform is only built for the single-rank path so far"); return -1; }
   const int p1 = c->p1, p2 = c->p2, T = st->T, W = st->ring - 1;
   const int Nx = po->Nx, Ny = po->Ny, Nz = po->Nz;
   const size_t esz = st->esz;
@@ -971,17 +1161,8 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         d.ncols = c->m2; d.nb1 = myT;
         d.in_axis_stride = 1; d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.in_contig = 1;
-        if (st->slab_zyx) {
-          /* panel = 8 x-lines at one y; per-peer block [z_l][y][x_t]: x fastest, so that the
-           * y pass can emit x-contiguous segments and the x pass reads whole lines */
-          d.ncols = myT; d.nb1 = c->m2;
-          d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1];
-          d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
-          d.out_contig = 0;
-        } else {
-          d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
-          d.out_contig = 1;
-        }
+        d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
+        d.out_contig = 1;
         if (p2 > 1) { /* peer a owns z in [a*F3, ..): offt-compute.c:1015-1027 */
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
@@ -996,7 +1177,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         for (int a = 0; a < p2; a++) {
           sp[a] = (char *)st->send1[r] + (size_t)a * st->blk1 * esz;
           rp[a] = (char *)st->recv1[r] + (size_t)a * st->blk1 * esz;
-          sb[a] = rb[a] = (size_t)(st->slab_zyx ? T : myT) * c->M2 * c->M3 * esz;
+          sb[a] = rb[a] = (size_t)myT * c->M2 * c->M3 * esz;
         }
         if (myT > 0 && be->a2a(st, 1, p2, peers1, sp, sb, rp, rb, st->s_comm1)) return -1;
         be->event_record(st->ev_a1[r], st->s_comm1);
@@ -1012,22 +1193,14 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         offt_pass_desc d;
         desc_init(&d, st, Ny, dir, 1);
         void *k2dst;
-        if (st->slab_zyx) {
-          /* recv1 block [z_l][y_l][x_t] -> recv2 [z_l][y][x]: columns = x of this tile */
-          d.ncols = myT; d.nb1 = c->m3;
-          d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T;
-          d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1;
-          k2dst = (char *)st->recv2 + (size_t)x0 * esz;
-        } else {
-          d.ncols = c->m3; d.nb1 = myT;
-          d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3;
-          d.out_axis_stride = c->M3; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M3;
-          if (p1 > 1) {
-            d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
-            d.out_block_stride = (long long)st->blk2;
-          }
-          k2dst = (char *)st->send2 + (size_t)x0 * c->M4 * c->M3 * esz;
+        d.ncols = c->m3; d.nb1 = myT;
+        d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3;
+        d.out_axis_stride = c->M3; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M3;
+        if (p1 > 1) {
+          d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
+          d.out_block_stride = (long long)st->blk2;
         }
+        k2dst = (char *)st->send2 + (size_t)x0 * c->M4 * c->M3 * esz;
         if (p2 > 1) {
           d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0;
           d.in_block_stride = (long long)st->blk1;
@@ -1063,17 +1236,11 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     desc_init(&d, st, Nx, dir, 0);
     d.ncols = c->m3; d.nb1 = c->m4;
     d.in_axis_stride = (long long)c->M4 * c->M3; d.in_col_stride = 1; d.in_b1_stride = c->M3;
-    if (st->slab_zyx) { /* recv2 [z_l][y][x] -> out [z][y][x]: whole contiguous lines both sides */
-      d.ncols = c->m4; d.nb1 = c->m3;
-      d.in_axis_stride = 1; d.in_col_stride = c->M1; d.in_b1_stride = (long long)c->M4 * c->M1;
-      d.in_contig = 1;
-    }
     if (p1 > 1) {
       d.in_split = c->F1; d.in_split_nfloor = c->b1 ? p1 - c->b1 : 0;
       d.in_block_stride = (long long)st->blk2;
     }
     d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
-    if (st->slab_zyx) { d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2]; }
     d.out_contig = (c->ostride[0] == 1);
     d.scale = st->out_scale;
     if (be->pass(&d, st->recv2, data, s)) return -1;
@@ -1109,7 +1276,10 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     staged = 1;
   }
   be->event_record(st->ev0, st->s_compute);
-  int rc = st->use_pipeline ? execute_pipeline(po, data, direction) : execute_single(po, data, direction);
+  int rc;
+  if (!st->use_pipeline) rc = execute_single(po, data, direction);
+  else if (direction > 0) { SET_ERR("inverse transform is only built for the single-rank path so far"); rc = -1; }
+  else rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, direction);
   be->event_record(st->ev1, st->s_compute);
   if (rc) { t[ALL] = 99999999.0; return; } /* the reference's failure marker, offt-compute.c:3881 */
   if (st->async && !staged) { t[ALL] = wall_seconds() - t0; return; }
@@ -1118,7 +1288,11 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
   double a = 1e-3 * be->event_ms(st->evp[0], st->evp[1]);
   double b = 1e-3 * be->event_ms(st->evp[1], st->evp[2]);
   double cc = 1e-3 * be->event_ms(st->evp[2], st->evp[3]);
-  if (st->use_pipeline) {
+  if (st->use_pipeline && st->slab_zyx) {
+    /* K1 phase (all FFTz + pack), then the chunked exchange / FFTy / FFTx phase */
+    st->pass_s[0] = a; st->pass_s[1] = 0; st->pass_s[2] = b;
+    t[PACK1] = a; t[FFTx] = b;
+  } else if (st->use_pipeline) {
     double ph1 = 1e-3 * be->event_ms(st->evp[0], st->evp[2]);
     st->pass_s[0] = ph1; st->pass_s[1] = 0; st->pass_s[2] = cc;
     t[PACK1] = ph1; t[FFTx] = cc;

@@ -173,7 +173,8 @@ def test_forced_tile_pipeline_on_one_gpu(built, monkeypatch):
     """the multi-rank code path (tile ring, fused pack/unpack descriptors, streams/events) with p = 1"""
     monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
     for shape, kw in [((64, 64, 64), dict(T1=4, W1=2)), ((32, 16, 64), dict(T1=5, W1=1, S=1)), ((20, 12, 18), dict(T1=3, W1=0)),
-                      ((128, 128, 128), dict())]:
+                      ((128, 128, 128), dict()), ((64, 64, 64), dict(T1=24, T2=5)), ((256, 32, 64), dict(T1=64, T2=16)),
+                      ((20, 12, 18), dict(T1=3, T2=4))]:
         got, _ = gpu_fft(shape, **kw)
         want, _, _ = O.world_fft(*shape, 1, kind=1, **kw)
         check64(got, want)

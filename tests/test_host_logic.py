@@ -54,7 +54,7 @@ def test_single_rank_direct(cpu1, shape, layout):
 def test_single_rank_forced_pipeline(cpu1, monkeypatch):
     monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
     for shape, kw in [((8, 8, 8), dict(T1=2, W1=1)), ((12, 6, 10), dict(T1=5, W1=2)), ((8, 8, 8), dict(T1=3, W1=0, S=1)),
-                      ((4, 4, 4), dict(T1=100))]:
+                      ((4, 4, 4), dict(T1=100)), ((12, 6, 10), dict(T1=5, T2=3)), ((9, 4, 7), dict(T1=2, T2=1))]:
         c, v, buf = cpu_world.run_rank(*shape, **kw)
         G = np.zeros(shape, dtype=np.complex128)
         cpu_world.scatter_out(c, buf, G)
@@ -172,7 +172,10 @@ def test_gloo_world2(built, tmp_path):
              dict(N=[8, 8, 8], params=dict(P1=1, S=1, T1=2, W1=1)), dict(N=[8, 8, 8], params=dict(P1=2), eq=1),
              dict(N=[9, 7, 5], params=dict(P1=2, T1=2, W1=2)), dict(N=[9, 7, 5], params=dict(P1=1, T1=4, W1=0, S=1)),
              dict(N=[16, 16, 4], params=dict()),
-             dict(N=[8, 8, 8], params=dict(P1=1), r2c=1), dict(N=[8, 6, 12], params=dict(P1=2, S=1), r2c=1)]
+             dict(N=[8, 8, 8], params=dict(P1=1), r2c=1), dict(N=[8, 6, 12], params=dict(P1=2, S=1), r2c=1),
+             # slab schedule with several z-chunks and a ragged last x-tile / z-chunk
+             dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2)), dict(N=[16, 8, 16], params=dict(P1=1, T1=8, T2=1)),
+             dict(N=[7, 5, 11], params=dict(P1=1, T1=2, T2=4), r2c=1)]
     _run_world(2, cases, tmp_path)
 
 
