@@ -82,5 +82,7 @@ static const offt_backend k_cpu_backend = {cb_malloc, cb_free, cb_prepare, cb_pa
                                            cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd};
 
 const offt_backend *cpu_backend_table(void) { return &k_cpu_backend; }
+/* run one descriptor on host arrays (descriptor-level parity tests against the HIP kernels) */
+int cpu_backend_run_pass(const offt_pass_desc *d, const void *in, void *out) { return cb_pass(d, in, out, NULL); }
 void cpu_backend_set_a2a(a2a_cb_t cb) { g_a2a_cb = cb; }
 long cpu_backend_pass_count(void) { return g_pass_count; }

@@ -1,0 +1,121 @@
+"""-m gpu: the kernel ABI (offt_hipk_fft_pass) against the test-only CPU interpreter of pass descriptors,
+on randomised descriptors: every (in_contig, out_contig) flavour, per-peer splits on either side (power-of-two
+-> register kernels, uneven F/F+1 -> any-length kernel), both batch dimensions, ragged column panels, inverse,
+scale, real input, f32.  This is what the fused pack/unpack of the multi-GPU schedules rests on, and a one-GPU
+box cannot exercise those schedules with real peers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from offt_amd import api
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Desc(C.Structure):
+    _fields_ = [("n", C.c_int), ("precision", C.c_int), ("direction", C.c_int), ("ncols", C.c_int),
+                ("nb1", C.c_int), ("nb2", C.c_int),
+                ("in_axis_stride", C.c_longlong), ("in_col_stride", C.c_longlong), ("in_b1_stride", C.c_longlong),
+                ("in_b2_stride", C.c_longlong),
+                ("out_axis_stride", C.c_longlong), ("out_col_stride", C.c_longlong), ("out_b1_stride", C.c_longlong),
+                ("out_b2_stride", C.c_longlong),
+                ("in_split", C.c_int), ("in_split_nfloor", C.c_int), ("out_split", C.c_int), ("out_split_nfloor", C.c_int),
+                ("in_block_stride", C.c_longlong), ("out_block_stride", C.c_longlong),
+                ("in_contig", C.c_int), ("out_contig", C.c_int), ("variant", C.c_int), ("scale", C.c_double),
+                ("real_input", C.c_int)]
+
+
+def layout(rng, n, ncols, nb1, nb2, split, nfloor, contig):
+    """random non-overlapping strides for a [b2][b1][...] array whose inner two dims are (axis, col) in the order
+    `contig` asks for; with a split the axis is cut into blocks that sit `block_stride` apart"""
+    nblk = 1
+    inner = n
+    if split or nfloor:
+        big = split + (1 if nfloor else 0)
+        nblk = nfloor + (n - split * nfloor + big - 1) // big if nfloor else (n + split - 1) // split
+        inner = big
+    pad = int(rng.integers(0, 3))
+    if contig:
+        axis, col = 1, inner + pad
+        plane = col * ncols
+    else:
+        col, axis = 1, ncols + pad
+        plane = axis * inner
+    blk = plane + int(rng.integers(0, 5))
+    b1 = blk * nblk + int(rng.integers(0, 4))
+    b2 = b1 * nb1 + int(rng.integers(0, 4))
+    total = b2 * nb2 + 8
+    return dict(axis=axis, col=col, b1=b1, b2=b2, blk=blk if (split or nfloor) else 0, total=total)
+
+
+def make_case(rng, n, prec):
+    d = Desc()
+    d.n, d.precision = n, prec
+    d.direction = int(rng.choice([-1, -1, 1]))
+    d.ncols, d.nb1, d.nb2 = int(rng.integers(1, 21)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    d.in_contig, d.out_contig = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    d.variant = -1
+    d.scale = float(rng.choice([1.0, 0.5, 1.0 / n]))
+    d.real_input = 0
+
+    def pick_split():
+        kind = rng.integers(0, 3)
+        if kind == 0 or n < 4:
+            return 0, 0
+        if kind == 1:  # even split
+            cands = [f for f in range(1, n) if n % f == 0]
+            return int(rng.choice(cands)), 0
+        p = int(rng.integers(2, min(n, 6) + 1))  # uneven: first p-b peers hold F, the rest F+1 (offt-compute.c:132-144)
+        F, b = n // p, n % p
+        return (F, p - b) if b else (F, 0)
+    d.in_split, d.in_split_nfloor = pick_split()
+    d.out_split, d.out_split_nfloor = pick_split()
+    if rng.integers(0, 6) == 0 and d.direction < 0:  # real-input z pass
+        d.real_input, d.in_contig, d.in_split, d.in_split_nfloor = 1, 1, 0, 0
+    li = layout(rng, n, d.ncols, d.nb1, d.nb2, d.in_split, d.in_split_nfloor, d.in_contig)
+    lo = layout(rng, n, d.ncols, d.nb1, d.nb2, d.out_split, d.out_split_nfloor, d.out_contig)
+    if d.real_input:  # rows of n/2+1 complex slots hold n reals
+        li = layout(rng, n // 2 + 1, d.ncols, d.nb1, d.nb2, 0, 0, 1)
+    d.in_axis_stride, d.in_col_stride, d.in_b1_stride, d.in_b2_stride, d.in_block_stride = li["axis"], li["col"], li["b1"], li["b2"], li["blk"]
+    d.out_axis_stride, d.out_col_stride, d.out_b1_stride, d.out_b2_stride, d.out_block_stride = lo["axis"], lo["col"], lo["b1"], lo["b2"], lo["blk"]
+    return d, li["total"], lo["total"]
+
+
+@pytest.fixture(scope="module")
+def libs(built):
+    L = api.lib()
+    L.offt_hipk_fft_pass.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.offt_hipk_prepare.argtypes = [C.c_int, C.c_int]
+    L.offt_hipk_last_error.restype = C.c_char_p
+    CB = C.CDLL(os.path.join(ROOT, "tests", "libcpubackend.so"))
+    CB.cpu_backend_run_pass.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p]
+    return L, CB
+
+
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 6, 12, 18, 30, 100, 127, 384])
+def test_random_descriptors(libs, n):
+    L, CB = libs
+    rng = np.random.default_rng(1000 + n)
+    for prec in (api.F64, api.F32):
+        assert L.offt_hipk_prepare(n, prec) == 0
+        ft, ct = (np.float64, np.complex128) if prec == api.F64 else (np.float32, np.complex64)
+        for _ in range(6 if n <= 512 else 3):
+            d, nin, nout = make_case(rng, n, prec)
+            src = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(ct)
+            want = np.full(nout, 7 - 3j, dtype=ct)  # sentinel: untouched elements must stay untouched
+            assert CB.cpu_backend_run_pass(C.byref(d), src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p)) == 0
+            din = torch.from_numpy(src.view(ft).copy()).cuda()
+            dout = torch.from_numpy(np.full(nout, 7 - 3j, dtype=ct).view(ft).copy()).cuda()
+            torch.cuda.synchronize()
+            rc = L.offt_hipk_fft_pass(C.byref(d), din.data_ptr(), dout.data_ptr(), None)
+            assert rc == 0, L.offt_hipk_last_error()
+            torch.cuda.synchronize()
+            got = dout.cpu().numpy().view(ct)
+            tol = 1e-13 if prec == api.F64 else 5e-6
+            scale = np.abs(want).max()
+            desc = {f: getattr(d, f) for f, _ in Desc._fields_}
+            assert np.abs(got - want).max() <= tol * scale * max(1.0, np.log2(n)), desc
