@@ -50,3 +50,15 @@ ifeq ($(MPI),1)
 else
 	$(CC) -std=gnu11 -O2 -Wall -Iinclude -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib
 endif
+
+# host logic under AddressSanitizer + UBSan on the CPU test backend (GPU ASan is not available on the pool)
+asan-test: $(BUILD)/offt_kernels.o
+	mkdir -p $(BUILD)/asan
+	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude -c $(CSRC)/offt_host.c -o $(BUILD)/asan/offt_host.o
+	g++ -shared -fsanitize=address,undefined -o $(BUILD)/asan/liboffthip.so $(BUILD)/offt_kernels.o $(BUILD)/asan/offt_host.o -Wl,--allow-shlib-undefined -ldl -lm -lpthread
+	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fPIC -shared -Ioracle -I$(CSRC) -o $(BUILD)/asan/libcpubackend.so tests/cpu_backend.c oracle/oracle_fft.c -lm
+	cp tests/libcpubackend.so $(BUILD)/asan/libcpubackend.so.orig
+	cp $(BUILD)/asan/libcpubackend.so tests/libcpubackend.so
+	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
+	  OFFT_AMD_LIB=$(CURDIR)/$(BUILD)/asan/liboffthip.so python -m pytest tests/test_host_logic.py -x -q; \
+	  rc=$$?; cp $(BUILD)/asan/libcpubackend.so.orig tests/libcpubackend.so; exit $$rc
