@@ -1063,15 +1063,25 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     /* ---- a2a(h, i): communicate_a2a (offt-compute.c:862-881), chunk-major ---- */
     if (st->x1) {
       if (h >= 2) be->stream_wait(sc, st->ev_sc[slot]); /* receive slot consumed by K2(h-2) */
-      for (int i = 0; i < nt; i++) {
-        if (h == 0) be->stream_wait(sc, st->ev_s1[i]);
-        const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2];
-        for (int a = 0; a < p2; a++) {
-          sp[a] = (char *)st->S1 + (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
-          rp[a] = (char *)st->R1[slot] + ((size_t)i * p2 + a) * st->sblkR * esz;
-          sb[a] = rb[a] = (size_t)tzh * c->M2 * T * esz;
+      /* chunk 0 goes tile by tile, right behind the K1 that produced the tile; later chunks
+       * have everything ready and go out as ONE grouped call (nt * p2 pieces): fewer, larger
+       * RCCL launches keep the host enqueue cost well below the transfer time */
+      const int groups = (h == 0) ? nt : 1, per = (h == 0) ? 1 : nt;
+      for (int g = 0; g < groups; g++) {
+        const int cnt = per * p2;
+        const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
+        if (h == 0) be->stream_wait(sc, st->ev_s1[g]);
+        for (int ii = 0; ii < per; ii++) {
+          const int i = (h == 0) ? g : ii;
+          for (int a = 0; a < p2; a++) {
+            const int e = ii * p2 + a;
+            pr[e] = peers[a];
+            sp[e] = (char *)st->S1 + (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
+            rp[e] = (char *)st->R1[slot] + ((size_t)i * p2 + a) * st->sblkR * esz;
+            sb[e] = rb[e] = (size_t)tzh * c->M2 * T * esz;
+          }
         }
-        if (be->a2a(st, 1, p2, peers, sp, sb, rp, rb, sc)) return -1;
+        if (be->a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
       }
       be->event_record(st->ev_sa[slot], sc);
       be->stream_wait(s, st->ev_sa[slot]);

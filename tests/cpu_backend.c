@@ -13,7 +13,7 @@
 #include "offt_backend.h"
 #include "oracle.h"
 
-typedef int (*a2a_cb_t)(int which, int npeers, const void *const *sendp, const size_t *sendbytes,
+typedef int (*a2a_cb_t)(int which, int npeers, const int *peer, const void *const *sendp, const size_t *sendbytes,
                         void *const *recvp, const size_t *recvbytes);
 static a2a_cb_t g_a2a_cb = NULL;
 static long g_pass_count = 0;
@@ -71,9 +71,9 @@ static int cb_stream_sync(void *s) { (void)s; return 0; }
 static double cb_event_ms(void *a, void *b) { (void)a; (void)b; return 0.0; }
 static int cb_a2a(void *ctx, int which, int npeers, const int *peer, const void *const *sendp, const size_t *sendbytes,
                   void *const *recvp, const size_t *recvbytes, void *stream) {
-  (void)ctx; (void)peer; (void)stream;
+  (void)ctx; (void)stream;
   if (!g_a2a_cb) return -1;
-  return g_a2a_cb(which, npeers, sendp, sendbytes, recvp, recvbytes);
+  return g_a2a_cb(which, npeers, peer, sendp, sendbytes, recvp, recvbytes);
 }
 static int cb_memcpy_dd(void *dst, const void *src, size_t bytes, void *s) { (void)s; memmove(dst, src, bytes); return 0; }
 

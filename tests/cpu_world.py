@@ -12,7 +12,7 @@ import oracle_lib as O
 from offt_amd import api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-A2A_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+A2A_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _keep = {}
 
@@ -34,14 +34,15 @@ def install(rank=0, size=1, p1=None, dist=None):
     L = api.lib()
     L.offt_hip_test_set_backend.argtypes = [C.c_void_p, C.c_int, C.c_int]
 
-    def a2a(which, npeers, sendp, sendbytes, recvp, recvbytes):
+    def a2a(which, npeers, peer_in_group, sendp, sendbytes, recvp, recvbytes):
         try:
             import torch
             p2 = size // p1 if p1 else size
             rx, ry = rank // p2, rank % p2
             reqs, keep = [], []
             for a in range(npeers):
-                peer = rx * p2 + a if which == 1 else a * p2 + ry
+                g = peer_in_group[a]  # rank inside the row (which == 1) / column (which == 2) group
+                peer = rx * p2 + g if which == 1 else g * p2 + ry
                 sb, rb = sendbytes[a], recvbytes[a]
                 if peer == rank:
                     assert sb == rb

@@ -193,3 +193,13 @@ def test_gloo_world8(built, tmp_path):
              dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[16, 16, 16], params=dict(P1=1), r2c=1),
              dict(N=[16, 16, 16], params=dict(P1=4), eq=1)]
     _run_world(8, cases, tmp_path)
+
+
+def test_baseline_config0_128cube_two_ranks(built, tmp_path):
+    """BASELINE.json configs[0]: 128^3 double-complex on 2 ranks, CPU plumbing (no GPU): the product's host
+    pipeline over gloo with the reference's default parameters (P1=1, T1=8, W1=2 -- survey_recorded.json)."""
+    _run_world(2, [dict(N=[128, 128, 128], params=dict())], tmp_path)
+    import json
+    meta = json.load(open(tmp_path / "case0_rank0.json"))
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_recorded.json")))
+    assert {n: meta["v"][i] for i, n in enumerate(O.PARAM_NAMES)} == rec["default_params_N128_p2"]
