@@ -604,6 +604,11 @@ void build_registry() {
   reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
   reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
 #ifdef OFFT_DEV_F32
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, false>(2, 0);
+  reg_variant<float, 1024, 16, 16, 16, 4, 16, true>(3, 0);
+  reg_variant<float, 1024, 16, 16, 16, 4, 16, false>(4, 0);
   reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
   reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, 0);
   reg_variant<float, 2048, 32, 16, 16, 8, 8, true>(2, 0);
@@ -646,8 +651,14 @@ void build_registry() {
   reg_variant<float, 64, 8, 8, 8, 1, 16, false>(0);
   reg_variant<float, 128, 16, 16, 8, 1, 16, false>(0);
   reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
-  reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0);
-  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0);
+  // f32 moves twice the elements per HBM byte, so LDS/issue work per byte doubles: the
+  // contiguous/contiguous flavour is fastest with a packed (one 8-B op per element) exchange
+  // on a narrow 8-column panel (2.75 vs 3.63 ms at 1024^3); the flavours with a strided
+  // side keep 16 columns (128-B segments) and the split exchange.  profiles/r01_sweep.txt
+  reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
   reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
   reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
 #endif
