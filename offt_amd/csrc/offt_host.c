@@ -320,7 +320,7 @@ typedef struct hip_state {
   int use_pipeline;     /* 0: single-rank direct 3-pass path, 1: tile pipeline */
   const offt_backend *be;
   void *s_compute; int own_stream;
-  void *s_comm1, *s_comm2, *s_k1;
+  void *s_comm1, *s_comm2;
   void *ev0, *ev1, *evp[4];
   void *work; size_t work_elems; /* single path: transposed-output scratch */
   /* pipeline */
@@ -336,7 +336,7 @@ typedef struct hip_state {
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   void **send1, **recv1; /* ring */
   void **ev_k1, **ev_a1, **ev_k2;
-  void *ev_a2_last, *ev_k3;
+  void *ev_a2_last;
   void *send2, *recv2;
   ncclComm_t comm1, comm2; int have_comm1, have_comm2;
   void *stage; size_t stage_bytes;
@@ -500,9 +500,9 @@ static void state_free(hip_state *st) {
   be->dfree(st->stage);
   be->event_destroy(st->ev0); be->event_destroy(st->ev1);
   for (int i = 0; i < 4; i++) be->event_destroy(st->evp[i]);
-  be->event_destroy(st->ev_a2_last); be->event_destroy(st->ev_k3);
+  be->event_destroy(st->ev_a2_last);
   if (st->own_stream) be->stream_destroy(st->s_compute);
-  be->stream_destroy(st->s_comm1); be->stream_destroy(st->s_comm2); be->stream_destroy(st->s_k1);
+  be->stream_destroy(st->s_comm1); be->stream_destroy(st->s_comm2);
   if (st->have_comm1) R.CommDestroy(st->comm1);
   if (st->have_comm2) R.CommDestroy(st->comm2);
   free(st);
@@ -608,8 +608,8 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
       st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
       if (!st->recv2 || !st->send2) goto fail;
     }
-    st->ev_a2_last = be->event_create(); st->ev_k3 = be->event_create();
-    st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create(); st->s_k1 = be->stream_create();
+    st->ev_a2_last = be->event_create();
+    st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create();
     if (!g_backend && (po->p > 1 || force)) {
       /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
        * (stride p2) -- offt-compute.c:78-125 */
@@ -1137,7 +1137,6 @@ static int execute_slab(struct _offt_plan *po, void *data) {
 /* with the second exchange streaming behind the first there is no separate  */
 /* phase 2 loop.  Three HBM round trips per element in total.                */
 /* ------------------------------------------------------------------------- */
-static int peer_m(int a, int F, int b, int p) { return blk_size(a, F, b, p); }
 
 static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   hip_state *st = (hip_state *)po->hip_state;
@@ -1156,14 +1155,13 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
    * K2(i-W), so that tile i's exchange runs under K1(i+1..i+W).  (Putting K1 and K2 on
    * two streams was measured and is slower: cross-stream event edges cost more than the
    * tail waves they fill -- profiles/r01_sweep.txt.) */
-  void *sA = s;
   be->event_record(st->evp[0], s);
   for (int i = 0; i < st->ntiles + W; i++) {
     if (i < st->ntiles) {
       /* ---- K1(i): FFTz + pack1 (offt-compute.c:905-1206) ---- */
       const int r = i % st->ring, x0 = i * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
-      if (i >= st->ring) be->stream_wait(sA, st->ev_k2[r]); /* slot's previous tile fully consumed */
+      if (i >= st->ring) be->stream_wait(s, st->ev_k2[r]); /* slot's previous tile fully consumed */
       if (myT > 0 && c->m2 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Nz, dir, 2);
@@ -1177,9 +1175,9 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
         }
-        if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], sA)) return -1;
+        if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s)) return -1;
       }
-      be->event_record(st->ev_k1[r], sA);
+      be->event_record(st->ev_k1[r], s);
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
       if (st->x1) {
         be->stream_wait(st->s_comm1, st->ev_k1[r]);
@@ -1224,7 +1222,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         const void *sp[p1]; void *rp[p1]; size_t sb[p1], rb[p1];
         int any = 0;
         for (int a = 0; a < p1; a++) {
-          int ma = peer_m(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
+          int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
           sp[a] = (char *)st->send2 + ((size_t)a * st->blk2 + (size_t)x0 * c->M4 * c->M3) * esz;
           rp[a] = (char *)st->recv2 + ((size_t)a * st->blk2 + (size_t)x0 * c->M4 * c->M3) * esz;
           sb[a] = (size_t)myT * c->M4 * c->M3 * esz;
