@@ -40,6 +40,12 @@ typedef struct offt_backend {
 
 void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
 
+/* keep the HIP backend but route the exchange through `fn` (called with the comm stream
+ * drained; device pointers): several test ranks can then share one GPU */
+typedef int (*offt_test_transport_fn)(int which, int npeers, const int *peer, const void *const *sendp,
+                                      const size_t *sendbytes, void *const *recvp, const size_t *recvbytes);
+void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -386,11 +386,24 @@ static double hb_event_ms(void *a, void *b) {
   }
   return ms;
 }
+/* test-only transport override (offt_backend.h): the HIP kernels, streams and events stay,
+ * only the exchange goes through a callback.  Lets several ranks share ONE GPU (RCCL refuses
+ * duplicate devices) so the multi-rank schedules run on real device memory in -m gpu tests. */
+static offt_test_transport_fn g_test_transport = NULL;
+void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size) {
+  g_test_transport = fn;
+  G.rank = fn ? rank : 0; G.size = fn ? size : 1; G.have_comm = 0;
+}
+
 /* all-to-all of one tile inside a row/column group (communicate_a2a(v),
  * offt-compute.c:835-881): grouped ncclSend/ncclRecv over xGMI */
 static int hb_a2a(void *ctx, int which, int npeers, const int *peer_rank_in_comm, const void *const *sendp,
                   const size_t *sendbytes, void *const *recvp, const size_t *recvbytes, void *stream) {
   hip_state *st = (hip_state *)ctx;
+  if (g_test_transport) { /* synchronous, host-staged by the test */
+    HCHECK(hipStreamSynchronize((hipStream_t)stream), return -1);
+    return g_test_transport(which, npeers, peer_rank_in_comm, sendp, sendbytes, recvp, recvbytes);
+  }
   ncclComm_t cm = which == 1 ? st->comm1 : st->comm2;
   NCHECK(R.GroupStart(), return -1);
   for (int a = 0; a < npeers; a++) {
@@ -610,7 +623,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     }
     st->ev_a2_last = be->event_create();
     st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create();
-    if (!g_backend && (po->p > 1 || force)) {
+    if (!g_backend && !g_test_transport && (po->p > 1 || force)) {
       /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
        * (stride p2) -- offt-compute.c:78-125 */
       if (!G.have_comm) { SET_ERR("offt_3d_init: world of %d ranks but no RCCL communicator (offt_hip_set_world)", po->p); goto fail; }

@@ -1,0 +1,58 @@
+"""-m gpu: the multi-rank schedules (slab and pencil) with 2 and 4 ranks SHARING the one GPU of the test box.
+Every kernel launch, descriptor, device buffer, stream and event is the product's; only the transport is
+swapped (RCCL refuses two ranks on one device) for a host-staged gloo exchange.  Results are gathered
+through ostart/osize/ostride and compared with numpy.fft and the oracle on the same decomposition."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cpu_world
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(size, cases, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(size):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_world_worker.py"),
+                                       json.dumps(cases), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    for ci, case in enumerate(cases):
+        shape = tuple(case["N"])
+        r2c = case.get("r2c", 0)
+        oshape = (shape[0], shape[1], shape[2] // 2 + 1) if r2c else shape
+        G = np.full(oshape, np.nan + 0j)
+        for r in range(size):
+            meta = json.load(open(tmp_path / f"case{ci}_rank{r}.json"))
+            cpu_world.scatter_out(meta["comm"], np.load(tmp_path / f"case{ci}_rank{r}.npy"), G)
+        assert not np.isnan(G).any(), case
+        want = np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2)) if r2c else np.fft.fftn(O.hash_field(*shape))
+        assert np.linalg.norm(G - want) / np.linalg.norm(want) < 1e-13, case
+        og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **case["params"])
+        assert np.linalg.norm(G - og) / np.linalg.norm(og) < 1e-13, case
+
+
+def test_two_ranks_one_gpu(built, tmp_path):
+    cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[64, 64, 64], params=dict(P1=2)),
+             dict(N=[128, 64, 32], params=dict(P1=1, T1=16, T2=4)), dict(N=[64, 64, 64], params=dict(P1=1, S=1)),
+             dict(N=[64, 64, 64], params=dict(P1=2), eq=1), dict(N=[18, 20, 14], params=dict(P1=1, T1=4, T2=3)),
+             dict(N=[64, 32, 128], params=dict(P1=1), r2c=1), dict(N=[256, 256, 256], params=dict(P1=1))]
+    run_world(2, cases, tmp_path)
+
+
+def test_four_ranks_one_gpu(built, tmp_path):
+    cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[64, 64, 64], params=dict(P1=2)),
+             dict(N=[64, 64, 64], params=dict(P1=4, S=1)), dict(N=[128, 128, 128], params=dict(P1=1)),
+             dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[128, 128, 128], params=dict())]
+    run_world(4, cases, tmp_path)
