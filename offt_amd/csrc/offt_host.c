@@ -328,10 +328,10 @@ typedef struct hip_state {
   int slab_zyx;          /* p1 == 1 and z-y-x output: single-exchange slab schedule, see execute_slab() */
   int t1_custom, t2_custom; /* the caller fixed T1 / T2 (run-fft -T / -t): use them as given */
   int sT, sTz, sNt, sH;  /* slab schedule: x-tile, z-chunk thickness, #tiles, #chunks */
-  size_t sblkS, sblkR;   /* elements per (tile, peer) block in S1 / in a chunk buffer */
-  void *S1, *R1[2], *R2; /* packed send volume, double-buffered chunk receive, y-transformed volume */
+  size_t sblkS;          /* elements per (tile, peer) block of S1 / R1: [z_l][y][x_t] */
+  void *S1, *R1, *R2;    /* packed send volume, receive volume (same layout), y-transformed volume */
   void **ev_s1;          /* per x-tile: K1 done */
-  void *ev_sa[2], *ev_sc[2]; /* per chunk slot: all messages arrived / chunk consumed */
+  void **ev_sa;          /* per z-chunk: every tile's share of the chunk has arrived */
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   void **send1, **recv1; /* ring */
@@ -982,12 +982,17 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 /* unpack2 + FFTx, offt-compute.c:3682-3862) only needs the planes it works   */
 /* on.  So the exchange is ordered z-chunk-major:                            */
 /*   K1(i)     FFTz of x-tile i, stored per peer as [z_l][y][x_t]   (all i)   */
-/*   a2a(h,i)  z-chunk h of tile i to every peer  (comm stream, back to back) */
-/*   K2(h)     FFTy of chunk h from the receive slot into R2[z_l][y][x]       */
+/*   a2a(h,i)  z-chunk h of tile i to every peer, chunk-major: chunk 0 tile   */
+/*             by tile behind K1(i), later chunks as one grouped call each    */
+/*   K2(h)     FFTy of chunk h from the receive volume into R2[z_l][y][x]     */
 /*   K3(h)     FFTx of chunk h, contiguous lines, into the caller's z-y-x     */
-/* K2(h)/K3(h) run while chunk h+1 is on the wire; only the last chunk's      */
-/* compute is exposed, instead of a whole x pass after the last tile.  Three  */
-/* HBM round trips, every kernel reads or writes whole lines or 128-B runs.   */
+/* The wire is busy from the end of K1(0) on and K2(h)/K3(h) run while later  */
+/* chunks are in flight, so only K1(0) and (if the links are the bottleneck)  */
+/* the last chunk's compute are exposed -- instead of a whole x pass after    */
+/* the last tile.  Three HBM round trips; every kernel reads or writes whole  */
+/* lines or 128-B runs.  (A tile-major order was tried: it delays chunk 0     */
+/* until all earlier tiles are fully sent and loses whenever the exchange     */
+/* takes longer than the K1 phase.)                                           */
 /* T1 / T2 keep their reference meaning (x-tile thickness of the exchange,    */
 /* z-thickness of the phase-2 work); unless the caller fixed them they are    */
 /* merged upwards until a per-peer message is at least 4 MiB -- the           */
@@ -995,15 +1000,13 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 /* ------------------------------------------------------------------------- */
 static void slab_teardown(hip_state *st) {
   const offt_backend *be = st->be;
-  be->dfree(st->S1); be->dfree(st->R1[0]); be->dfree(st->R1[1]); be->dfree(st->R2);
-  st->S1 = st->R1[0] = st->R1[1] = st->R2 = NULL;
+  be->dfree(st->S1); be->dfree(st->R1); be->dfree(st->R2);
+  st->S1 = st->R1 = st->R2 = NULL;
   for (int i = 0; i < st->sNt && st->ev_s1; i++) be->event_destroy(st->ev_s1[i]);
+  for (int h = 0; h < st->sH && st->ev_sa; h++) be->event_destroy(st->ev_sa[h]);
   free(st->ev_s1); st->ev_s1 = NULL;
-  for (int k = 0; k < 2; k++) {
-    be->event_destroy(st->ev_sa[k]); be->event_destroy(st->ev_sc[k]);
-    st->ev_sa[k] = st->ev_sc[k] = NULL;
-  }
-  st->sNt = 0;
+  free(st->ev_sa); st->ev_sa = NULL;
+  st->sNt = st->sH = 0;
 }
 
 static int slab_setup(struct _offt_plan *po, hip_state *st) {
@@ -1013,10 +1016,10 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   int T = po->params->v[_T1_], Tz = po->params->v[_T2_];
   if (T < 1) T = 1;
   if (Tz < 1) Tz = 1;
-  if (!st->t1_custom) { int t4 = (c->M1 + 3) / 4; if (T < t4) T = t4; }
+  if (!st->t1_custom) { int t4 = (c->M1 + 3) / 4; if (T < t4) T = t4; } /* 4 tiles: measured best kernel efficiency */
   if (T > c->M1) T = c->M1;
   if (!st->t2_custom) {
-    int t8 = (c->M3 + 7) / 8; if (Tz < t8) Tz = t8;
+    int z8 = (c->M3 + 7) / 8; if (Tz < z8) Tz = z8;
     while (Tz < c->M3 && (size_t)T * c->M2 * Tz * st->esz < min_msg) Tz *= 2;
   }
   if (Tz > c->M3) Tz = c->M3;
@@ -1024,18 +1027,17 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->sNt = (c->M1 + T - 1) / T;
   st->sH = (c->M3 + Tz - 1) / Tz;
   st->sblkS = (size_t)c->M3 * c->M2 * T;
-  st->sblkR = (size_t)Tz * c->M2 * T;
   st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
   st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
   if (!st->S1 || !st->R2) return -1;
-  if (st->x1)
-    for (int k = 0; k < 2; k++) {
-      st->R1[k] = be->dmalloc(st->sblkR * c->p2 * st->sNt * st->esz);
-      if (!st->R1[k]) return -1;
-    }
+  if (st->x1) {
+    st->R1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
+    if (!st->R1) return -1;
+  }
   st->ev_s1 = (void **)calloc(st->sNt, sizeof(void *));
+  st->ev_sa = (void **)calloc(st->sH, sizeof(void *));
   for (int i = 0; i < st->sNt; i++) st->ev_s1[i] = be->event_create();
-  for (int k = 0; k < 2; k++) { st->ev_sa[k] = be->event_create(); st->ev_sc[k] = be->event_create(); }
+  for (int h = 0; h < st->sH; h++) st->ev_sa[h] = be->event_create();
   return 0;
 }
 
@@ -1069,16 +1071,15 @@ static int execute_slab(struct _offt_plan *po, void *data) {
   }
   be->event_record(st->evp[1], s);
 
-  for (int h = 0; h < H; h++) {
-    const int slot = h & 1, z0 = h * Tz;
-    int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
-    int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
-    /* ---- a2a(h, i): communicate_a2a (offt-compute.c:862-881), chunk-major ---- */
-    if (st->x1) {
-      if (h >= 2) be->stream_wait(sc, st->ev_sc[slot]); /* receive slot consumed by K2(h-2) */
-      /* chunk 0 goes tile by tile, right behind the K1 that produced the tile; later chunks
-       * have everything ready and go out as ONE grouped call (nt * p2 pieces): fewer, larger
-       * RCCL launches keep the host enqueue cost well below the transfer time */
+  /* ---- exchange: communicate_a2a (offt-compute.c:862-881), z-chunk-major.  Chunk 0 goes tile by
+   * tile right behind the K1 that produced the tile; every later chunk has all tiles ready and
+   * goes out as ONE grouped call (nt * p2 pieces).  With t_K1 the K1 phase and C the time on the
+   * wire, chunk h lands at about t_K1(0) + (h+1) C/H and is needed at t_K1 + h (t_K2+t_K3)/H:
+   * the wire is never idle and compute only waits if the links are the bottleneck. ---- */
+  if (st->x1) {
+    for (int h = 0; h < H; h++) {
+      const int z0 = h * Tz;
+      int tz = c->M3 - z0; if (tz > Tz) tz = Tz;
       const int groups = (h == 0) ? nt : 1, per = (h == 0) ? 1 : nt;
       for (int g = 0; g < groups; g++) {
         const int cnt = per * p2;
@@ -1088,21 +1089,28 @@ static int execute_slab(struct _offt_plan *po, void *data) {
           const int i = (h == 0) ? g : ii;
           for (int a = 0; a < p2; a++) {
             const int e = ii * p2 + a;
+            const size_t off = (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
             pr[e] = peers[a];
-            sp[e] = (char *)st->S1 + (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
-            rp[e] = (char *)st->R1[slot] + ((size_t)i * p2 + a) * st->sblkR * esz;
-            sb[e] = rb[e] = (size_t)tzh * c->M2 * T * esz;
+            sp[e] = (char *)st->S1 + off;
+            rp[e] = (char *)st->R1 + off;
+            sb[e] = rb[e] = (size_t)tz * c->M2 * T * esz;
           }
         }
         if (be->a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
       }
-      be->event_record(st->ev_sa[slot], sc);
-      be->stream_wait(s, st->ev_sa[slot]);
+      be->event_record(st->ev_sa[h], sc);
     }
+  }
+
+  for (int h = 0; h < H; h++) {
+    const int z0 = h * Tz;
+    int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
+    int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
+    if (st->x1) be->stream_wait(s, st->ev_sa[h]);
     /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
     if (nz > 0) {
-      const char *src = st->x1 ? (const char *)st->R1[slot] : (const char *)st->S1 + (size_t)z0 * c->M2 * T * esz;
-      const size_t blk = st->x1 ? st->sblkR : st->sblkS;
+      const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (size_t)z0 * c->M2 * T * esz;
+      const size_t blk = st->sblkS;
       for (int part = 0; part < 2; part++) { /* full tiles in one launch, the ragged tile in another */
         const int ntile = part == 0 ? nfull : (tail > 0 ? 1 : 0);
         if (!ntile) continue;
@@ -1117,7 +1125,6 @@ static int execute_slab(struct _offt_plan *po, void *data) {
                      (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s)) return -1;
       }
     }
-    be->event_record(st->ev_sc[slot], s);
     /* ---- K3(h): FFTx (offt-compute.c:2729-2730) on whole lines, into the caller's z-y-x layout ---- */
     if (nz > 0 && c->m4 > 0) {
       offt_pass_desc d;

@@ -21,8 +21,8 @@ def run(shape, slab, T1=None, reps=4):
     E = shape[0] * shape[1] * shape[2]
     print(f"{shape} slab={slab} T1={T1}: total {best[0]*1e3:.3f} ms tiled {best[1][0]*1e3:.3f} K3 {best[1][2]*1e3:.3f}  alg {6*16*E/best[0]/1e9:.0f} GB/s", flush=True)
     api.offt_3d_fin(po)
-for shape in ((1024, 128, 1024), (1024, 1024, 128), (1024, 256, 512)):
-    for slab in (1, 0):
-        run(shape, slab)
-    run(shape, 1, T1=32)
-    run(shape, 0, T1=32)
+for shape in ((1024, 128, 1024), (1024, 1024, 128)):
+    for rep in range(2):
+        for T1 in (None, 64, 128, 256, 512):
+            run(shape, 1, T1=T1)
+    run(shape, 0)
