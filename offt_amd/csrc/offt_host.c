@@ -347,6 +347,7 @@ typedef struct hip_state {
   double last_dev_s, pass_s[3];
   int pass_slot[3];
   int warned_in;
+  struct step_list *rec; /* non-NULL: the schedule is being recorded, not run (multi-rank inverse) */
 } hip_state;
 
 /* ---- default backend: HIP + RCCL ----------------------------------------- */
@@ -975,6 +976,90 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* step recorder.  The multi-rank schedules issue their passes and exchanges   */
+/* through run_pass()/run_a2a().  Normally these launch at once; for the       */
+/* inverse transform (an extension: the reference is forward-only) the forward */
+/* schedule is recorded instead and then replayed BACKWARDS with every step    */
+/* mirrored: a pass swaps its input and output descriptors and flips the sign  */
+/* of the exponent, an exchange swaps its send and receive sides.  The forward */
+/* schedule is hazard-free, so its exact reverse is too; the replay runs in    */
+/* order on the compute stream (no overlap tuning for this extension).         */
+/* ------------------------------------------------------------------------- */
+typedef struct step {
+  int kind;               /* 0 = pass, 1 = exchange */
+  int first;              /* pass reads the caller's input layout (K1): it writes the inverse's result */
+  offt_pass_desc d; const void *src; void *dst;
+  int which, cnt; int *peer; const void **sp; size_t *sb; void **rp; size_t *rb;
+} step;
+typedef struct step_list { step *v; int n, cap; } step_list;
+
+static step *rec_new(step_list *l) {
+  if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 64; l->v = (step *)realloc(l->v, (size_t)l->cap * sizeof(step)); }
+  step *e = &l->v[l->n++];
+  memset(e, 0, sizeof *e);
+  return e;
+}
+static void rec_free(step_list *l) {
+  for (int i = 0; i < l->n; i++) { free(l->v[i].peer); free(l->v[i].sp); free(l->v[i].sb); free(l->v[i].rp); free(l->v[i].rb); }
+  free(l->v);
+  l->v = NULL; l->n = l->cap = 0;
+}
+
+static int run_pass(hip_state *st, const offt_pass_desc *d, const void *src, void *dst, void *stream, int first) {
+  if (!st->rec) return st->be->pass(d, src, dst, stream);
+  step *e = rec_new(st->rec);
+  e->kind = 0; e->first = first; e->d = *d; e->src = src; e->dst = dst;
+  return 0;
+}
+static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const void *const *sp, const size_t *sb,
+                   void *const *rp, const size_t *rb, void *stream) {
+  if (!st->rec) return st->be->a2a(st, which, cnt, peer, sp, sb, rp, rb, stream);
+  step *e = rec_new(st->rec);
+  e->kind = 1; e->which = which; e->cnt = cnt;
+  e->peer = (int *)malloc(sizeof(int) * cnt); e->sp = (const void **)malloc(sizeof(void *) * cnt);
+  e->rp = (void **)malloc(sizeof(void *) * cnt); e->sb = (size_t *)malloc(sizeof(size_t) * cnt); e->rb = (size_t *)malloc(sizeof(size_t) * cnt);
+  memcpy(e->peer, peer, sizeof(int) * cnt); memcpy(e->sp, sp, sizeof(void *) * cnt); memcpy(e->rp, rp, sizeof(void *) * cnt);
+  memcpy(e->sb, sb, sizeof(size_t) * cnt); memcpy(e->rb, rb, sizeof(size_t) * cnt);
+  return 0;
+}
+
+static int execute_slab(struct _offt_plan *po, void *data);
+static int execute_pipeline(struct _offt_plan *po, void *data, int dir);
+
+static int execute_inverse_multi(struct _offt_plan *po, void *data) {
+  hip_state *st = (hip_state *)po->hip_state;
+  const offt_backend *be = st->be;
+  void *s = st->s_compute;
+  if (po->is_r2c) { SET_ERR("complex-to-real inverse is not built (the reference has no inverse at all)"); return -1; }
+  step_list L = {NULL, 0, 0};
+  st->rec = &L;
+  int rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, -1);
+  st->rec = NULL;
+  be->event_record(st->evp[0], s);
+  for (int i = L.n - 1; i >= 0 && !rc; i--) {
+    step *e = &L.v[i];
+    if (e->kind == 0) {
+      offt_pass_desc d = e->d, f = e->d;
+      d.direction = +1;
+      d.in_axis_stride = f.out_axis_stride; d.in_col_stride = f.out_col_stride; d.in_b1_stride = f.out_b1_stride; d.in_b2_stride = f.out_b2_stride;
+      d.out_axis_stride = f.in_axis_stride; d.out_col_stride = f.in_col_stride; d.out_b1_stride = f.in_b1_stride; d.out_b2_stride = f.in_b2_stride;
+      d.in_split = f.out_split; d.in_split_nfloor = f.out_split_nfloor; d.in_block_stride = f.out_block_stride;
+      d.out_split = f.in_split; d.out_split_nfloor = f.in_split_nfloor; d.out_block_stride = f.in_block_stride;
+      d.in_contig = f.out_contig; d.out_contig = f.in_contig;
+      d.scale = e->first ? st->out_scale : 1.0;
+      rc = be->pass(&d, e->dst, (void *)e->src, s);
+    } else {
+      rc = be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, s);
+    }
+  }
+  be->event_record(st->evp[1], s);
+  be->event_record(st->evp[2], s);
+  be->event_record(st->evp[3], s);
+  rec_free(&L);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------- */
 /* slab schedule (p1 == 1, z-y-x output): ONE exchange, streamed in z-chunks   */
 /*                                                                           */
 /* With p1 == 1 every rank holds all x and all z of its y-block, there is no  */
@@ -1065,7 +1150,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       d.in_axis_stride = 1; d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1]; d.in_contig = 1;
       d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T; d.out_contig = 0;
       if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
-      if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, (char *)st->S1 + (size_t)i * p2 * st->sblkS * esz, s)) return -1;
+      if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, (char *)st->S1 + (size_t)i * p2 * st->sblkS * esz, s, 1)) return -1;
     }
     be->event_record(st->ev_s1[i], s);
   }
@@ -1096,7 +1181,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
             sb[e] = rb[e] = (size_t)tz * c->M2 * T * esz;
           }
         }
-        if (be->a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
+        if (run_a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
       }
       be->event_record(st->ev_sa[h], sc);
     }
@@ -1121,8 +1206,8 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T; d.in_b2_stride = (long long)p2 * blk;
         if (p2 > 1) { d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0; d.in_block_stride = (long long)blk; }
         d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
-        if (be->pass(&d, src + (size_t)first * p2 * blk * esz,
-                     (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s)) return -1;
+        if (run_pass(st, &d, src + (size_t)first * p2 * blk * esz,
+                     (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s, 0)) return -1;
       }
     }
     /* ---- K3(h): FFTx (offt-compute.c:2729-2730) on whole lines, into the caller's z-y-x layout ---- */
@@ -1133,7 +1218,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       d.in_axis_stride = 1; d.in_col_stride = c->M1; d.in_b1_stride = (long long)c->M4 * c->M1; d.in_contig = 1;
       d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2]; d.out_contig = 1;
       d.scale = st->out_scale;
-      if (be->pass(&d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s)) return -1;
+      if (run_pass(st, &d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
     }
   }
   be->event_record(st->evp[2], s);
@@ -1195,7 +1280,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
         }
-        if (be->pass(&d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s)) return -1;
+        if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s, 1)) return -1;
       }
       be->event_record(st->ev_k1[r], s);
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
@@ -1207,7 +1292,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           rp[a] = (char *)st->recv1[r] + (size_t)a * st->blk1 * esz;
           sb[a] = rb[a] = (size_t)myT * c->M2 * c->M3 * esz;
         }
-        if (myT > 0 && be->a2a(st, 1, p2, peers1, sp, sb, rp, rb, st->s_comm1)) return -1;
+        if (myT > 0 && run_a2a(st, 1, p2, peers1, sp, sb, rp, rb, st->s_comm1)) return -1;
         be->event_record(st->ev_a1[r], st->s_comm1);
       }
     }
@@ -1233,7 +1318,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0;
           d.in_block_stride = (long long)st->blk1;
         }
-        if (be->pass(&d, st->recv1[r], k2dst, s)) return -1;
+        if (run_pass(st, &d, st->recv1[r], k2dst, s, 0)) return -1;
       }
       be->event_record(st->ev_k2[r], s);
       /* ---- a2a2(k) over comm2: x-tile k of every column block ---- */
@@ -1249,7 +1334,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           rb[a] = (size_t)ma * c->M4 * c->M3 * esz;
           any |= (sb[a] || rb[a]);
         }
-        if (any && be->a2a(st, 2, p1, peers2, sp, sb, rp, rb, st->s_comm2)) return -1;
+        if (any && run_a2a(st, 2, p1, peers2, sp, sb, rp, rb, st->s_comm2)) return -1;
       }
     }
   }
@@ -1271,7 +1356,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
     d.out_contig = (c->ostride[0] == 1);
     d.scale = st->out_scale;
-    if (be->pass(&d, st->recv2, data, s)) return -1;
+    if (run_pass(st, &d, st->recv2, data, s, 0)) return -1;
   }
   be->event_record(st->evp[3], s);
   return 0;
@@ -1306,7 +1391,7 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
   be->event_record(st->ev0, st->s_compute);
   int rc;
   if (!st->use_pipeline) rc = execute_single(po, data, direction);
-  else if (direction > 0) { SET_ERR("inverse transform is only built for the single-rank path so far"); rc = -1; }
+  else if (direction > 0) rc = execute_inverse_multi(po, data);
   else rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, direction);
   be->event_record(st->ev1, st->s_compute);
   if (rc) { t[ALL] = 99999999.0; return; } /* the reference's failure marker, offt-compute.c:3881 */

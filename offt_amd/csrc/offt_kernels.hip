@@ -611,8 +611,9 @@ void build_registry() {
   reg_variant<float, 1024, 16, 16, 16, 4, 16, false>(4, 0);
   reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
   reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, 0);
-  reg_variant<float, 2048, 32, 16, 16, 8, 8, true>(2, 0);
-  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(3, 0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, 0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 8, false>(3, 0);
+  reg_variant<float, 2048, 32, 16, 16, 8, 4, false>(4, 0);
 #endif
 #ifdef OFFT_DEV_EXTRA
   reg_variant<double, 1024, 16, 4, 16, 16, 8, true>(2, 0);
@@ -659,7 +660,11 @@ void build_registry() {
   reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
   reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
   reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
-  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
+  // 2048 f32 (profiles/r01_sweep.txt): wide 16-column panels need E=64 to stay within 512 threads;
+  // the contiguous/contiguous flavour again prefers a narrow packed panel
+  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0, F_SS);
+  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
   reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
 #endif
 }

@@ -23,8 +23,12 @@ def main():
             import oracle_lib as O
             p1 = O.params_default(case["N"][0], case["N"][1], case["N"][2], size)[0]
         cpu_world.install(rank, size, p1=p1, dist=dist)
-        c, v, buf = cpu_world.run_rank(*case["N"], kind=1, is_equalxy=case.get("eq", 0), is_r2c=case.get("r2c", 0), **case["params"])
+        res = cpu_world.run_rank(*case["N"], kind=1, is_equalxy=case.get("eq", 0), is_r2c=case.get("r2c", 0),
+                                 roundtrip=bool(case.get("inv")), **case["params"])
+        c, v, buf = res[:3]
         np.save(os.path.join(outdir, f"case{ci}_rank{rank}.npy"), buf)
+        if case.get("inv"):
+            np.save(os.path.join(outdir, f"case{ci}_rank{rank}_inv.npy"), cpu_world.input_block(c, res[3]))
         json.dump({"comm": c, "v": v}, open(os.path.join(outdir, f"case{ci}_rank{rank}.json"), "w"))
         dist.barrier()
     cpu_world.uninstall()

@@ -77,8 +77,14 @@ def main():
             raise SystemExit("fill failed")
         api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
         buf = dev.cpu().numpy().view(np.complex128)
-        api.offt_3d_fin(po)
         np.save(os.path.join(outdir, f"case{ci}_rank{rank}.npy"), buf)
+        if case.get("inv"):
+            torch.cuda.synchronize()
+            api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+            import cpu_world
+            np.save(os.path.join(outdir, f"case{ci}_rank{rank}_inv.npy"),
+                    cpu_world.input_block(c, dev.cpu().numpy().view(np.complex128)))
+        api.offt_3d_fin(po)
         json.dump({"comm": c, "v": v}, open(os.path.join(outdir, f"case{ci}_rank{rank}.json"), "w"))
         dist.barrier()
     L.offt_hip_test_set_transport(None, 0, 1)

@@ -79,7 +79,7 @@ def uninstall():
     L.offt_hip_test_set_backend(None, 0, 1)
 
 
-def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, is_r2c=0, **params):
+def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, is_r2c=0, roundtrip=False, **params):
     """init + fill this rank's block on the host + execute; returns (comm dict, params, local result array)."""
     cp = api.make_params(**params)
     po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision, is_r2c=is_r2c)
@@ -102,7 +102,14 @@ def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, 
             buf[idx.ravel()] = f.astype(ct).ravel()
     ptr = buf.ctypes.data_as(C.c_void_p)
     api.offt_3d_execute_dir(po, ptr, ptr, direction)
+    back = None
+    if roundtrip:  # inverse of the result: must reproduce the input block times Nx*Ny*Nz
+        back = buf.copy()
+        bp = back.ctypes.data_as(C.c_void_p)
+        api.offt_3d_execute_dir(po, bp, bp, +1)
     api.offt_3d_fin(po)
+    if roundtrip:
+        return c, v, buf, back
     return c, v, buf
 
 
@@ -115,3 +122,11 @@ def scatter_out(c, buf, G):
     idx = np.arange(o0)[:, None, None] * s0 + np.arange(o1)[None, :, None] * s1 + np.arange(o2)[None, None, :] * s2
     G[c["ostart"][0]:c["ostart"][0] + o0, c["ostart"][1]:c["ostart"][1] + o1, c["ostart"][2]:c["ostart"][2] + o2] = \
         buf[idx.ravel()].reshape(o0, o1, o2)
+
+
+def input_block(c, buf):
+    """a rank's block read back through istart/isize/istride -> (array, global slices)"""
+    i0, i1, i2 = c["isize"]
+    s0, s1, s2 = c["istride"]
+    idx = np.arange(i0)[:, None, None] * s0 + np.arange(i1)[None, :, None] * s1 + np.arange(i2)[None, None, :] * s2
+    return buf[idx.ravel()].reshape(i0, i1, i2)

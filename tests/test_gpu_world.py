@@ -41,13 +41,20 @@ def run_world(size, cases, tmp_path):
         assert np.linalg.norm(G - want) / np.linalg.norm(want) < 1e-13, case
         og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **case["params"])
         assert np.linalg.norm(G - og) / np.linalg.norm(og) < 1e-13, case
+        if case.get("inv"):
+            for r in range(size):
+                meta = json.load(open(tmp_path / f"case{ci}_rank{r}.json"))["comm"]
+                back = np.load(tmp_path / f"case{ci}_rank{r}_inv.npy")
+                blk = O.hash_field(*meta["isize"], *meta["istart"])
+                assert np.linalg.norm(back / np.prod(shape) - blk) / np.linalg.norm(blk) < 1e-13, (case, r)
 
 
 def test_two_ranks_one_gpu(built, tmp_path):
     cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[64, 64, 64], params=dict(P1=2)),
              dict(N=[128, 64, 32], params=dict(P1=1, T1=16, T2=4)), dict(N=[64, 64, 64], params=dict(P1=1, S=1)),
              dict(N=[64, 64, 64], params=dict(P1=2), eq=1), dict(N=[18, 20, 14], params=dict(P1=1, T1=4, T2=3)),
-             dict(N=[64, 32, 128], params=dict(P1=1), r2c=1), dict(N=[256, 256, 256], params=dict(P1=1))]
+             dict(N=[64, 32, 128], params=dict(P1=1), r2c=1), dict(N=[256, 256, 256], params=dict(P1=1)),
+             dict(N=[64, 64, 64], params=dict(P1=1), inv=1), dict(N=[64, 32, 16], params=dict(P1=2, T1=8), inv=1)]
     run_world(2, cases, tmp_path)
 
 

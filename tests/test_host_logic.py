@@ -165,6 +165,14 @@ def _run_world(size, cases, tmp_path):
         # and against the restated reference pipeline on the same decomposition
         og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **case["params"])
         assert rel(G, og) < TOL, case
+        if case.get("inv"):  # offt_3d_execute_dir(+1) on the result gives back every rank's input block * N
+            for r in range(size):
+                meta = json.load(open(tmp_path / f"case{ci}_rank{r}.json"))["comm"]
+                back = np.load(tmp_path / f"case{ci}_rank{r}_inv.npy")
+                if back.size == 0:
+                    continue
+                blk = O.hash_field(*meta["isize"], *meta["istart"])
+                assert rel(back / np.prod(shape), blk) < TOL, (case, r)
 
 
 def test_gloo_world2(built, tmp_path):
@@ -175,7 +183,10 @@ def test_gloo_world2(built, tmp_path):
              dict(N=[8, 8, 8], params=dict(P1=1), r2c=1), dict(N=[8, 6, 12], params=dict(P1=2, S=1), r2c=1),
              # slab schedule with several z-chunks and a ragged last x-tile / z-chunk
              dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2)), dict(N=[16, 8, 16], params=dict(P1=1, T1=8, T2=1)),
-             dict(N=[7, 5, 11], params=dict(P1=1, T1=2, T2=4), r2c=1)]
+             dict(N=[7, 5, 11], params=dict(P1=1, T1=2, T2=4), r2c=1),
+             # multi-rank inverse (extension): slab and pencil schedules replayed backwards
+             dict(N=[8, 8, 8], params=dict(P1=1), inv=1), dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2), inv=1),
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=1), inv=1), dict(N=[9, 7, 5], params=dict(P1=2, S=1), inv=1)]
     _run_world(2, cases, tmp_path)
 
 
@@ -191,7 +202,8 @@ def test_gloo_world8(built, tmp_path):
     cases = [dict(N=[16, 16, 16], params=dict(P1=1)), dict(N=[16, 16, 16], params=dict()),
              dict(N=[16, 16, 16], params=dict(P1=8)), dict(N=[16, 16, 16], params=dict(P1=1, S=1, T1=4)),
              dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[16, 16, 16], params=dict(P1=1), r2c=1),
-             dict(N=[16, 16, 16], params=dict(P1=4), eq=1)]
+             dict(N=[16, 16, 16], params=dict(P1=4), eq=1), dict(N=[16, 16, 16], params=dict(P1=1), inv=1),
+             dict(N=[16, 16, 16], params=dict(), inv=1)]
     _run_world(8, cases, tmp_path)
 
 
