@@ -248,29 +248,45 @@ static void fftz_pack1(const orc_world *w, orank *R, int tile, int myT, double *
   for (int x = from_x; x < to_x; x++)
     for (int y = 0; y < m2; y++)
       fft_z_line(w, out + 2L * c->istride[1] * y + 2L * c->istride[0] * x, scr);
-  for (int x = from_x; x < to_x; x++)
-    for (int y = 0; y < m2; y++)
-      for (int z = 0; z < w->Nzn; z++) {
-        own_t o = owner(z, F3, b3, p2);
-        long B, dst;
-        int wide = (F3 * (p2 - b3) <= z);
-        if (S) { /* block [x][y][z-run], :1000-1032 */
-          int Sy, Sx;
-          if (is_a2av) {
-            B = wide ? (long)(p2 - b3) * (myT * m2 * F3) + (long)(o.a - (p2 - b3)) * (myT * m2 * (F3 + 1)) : (long)o.a * (myT * m2 * F3);
-            Sy = wide ? F3 + 1 : F3; Sx = m2 * Sy;
-          } else { B = (long)o.a * (myT * M2 * M3); Sy = M3; Sx = M2 * M3; }
-          dst = B + (z - o.off) + (long)y * Sy + (long)(x - from_x) * Sx;
-        } else { /* block [x][z][y], :1070-1109 */
-          int Sz, Sx;
-          if (is_a2av) {
-            B = wide ? (long)(p2 - b3) * (myT * m2 * F3) + (long)(o.a - (p2 - b3)) * (myT * m2 * (F3 + 1)) : (long)o.a * (myT * m2 * F3);
-            Sz = m2; Sx = wide ? m2 * (F3 + 1) : m2 * F3;
-          } else { B = (long)o.a * (myT * M2 * M3); Sz = M2; Sx = M2 * M3; }
-          dst = B + y + (long)(z - o.off) * Sz + (long)(x - from_x) * Sx;
-        }
-        memcpy(R->a2as + 2 * dst, out + 2L * z + 2L * c->istride[1] * y + 2L * c->istride[0] * x, 2 * sizeof(double));
-      }
+  /* the owner of a z index does not depend on (x, y): look it up once per call (the reference
+   * recomputes it per element, offt-compute.c:1000-1028; same values) */
+  own_t *own = (own_t *)malloc(sizeof(own_t) * (size_t)w->Nzn);
+  for (int z = 0; z < w->Nzn; z++) own[z] = owner(z, F3, b3, p2);
+#define PACK1_ELEM(x, y, z)                                                                                        \
+  do {                                                                                                             \
+    const own_t o = own[z];                                                                                        \
+    long B, dst;                                                                                                   \
+    const int wide = (F3 * (p2 - b3) <= (z));                                                                      \
+    if (S) { /* block [x][y][z-run], :1000-1032 */                                                                 \
+      int Sy, Sx;                                                                                                  \
+      if (is_a2av) {                                                                                               \
+        B = wide ? (long)(p2 - b3) * (myT * m2 * F3) + (long)(o.a - (p2 - b3)) * (myT * m2 * (F3 + 1)) : (long)o.a * (myT * m2 * F3); \
+        Sy = wide ? F3 + 1 : F3; Sx = m2 * Sy;                                                                     \
+      } else { B = (long)o.a * (myT * M2 * M3); Sy = M3; Sx = M2 * M3; }                                           \
+      dst = B + ((z) - o.off) + (long)(y) * Sy + (long)((x) - from_x) * Sx;                                        \
+    } else { /* block [x][z][y], :1070-1109 */                                                                     \
+      int Sz, Sx;                                                                                                  \
+      if (is_a2av) {                                                                                               \
+        B = wide ? (long)(p2 - b3) * (myT * m2 * F3) + (long)(o.a - (p2 - b3)) * (myT * m2 * (F3 + 1)) : (long)o.a * (myT * m2 * F3); \
+        Sz = m2; Sx = wide ? m2 * (F3 + 1) : m2 * F3;                                                              \
+      } else { B = (long)o.a * (myT * M2 * M3); Sz = M2; Sx = M2 * M3; }                                           \
+      dst = B + (y) + (long)((z) - o.off) * Sz + (long)((x) - from_x) * Sx;                                        \
+    }                                                                                                              \
+    const double *e_ = out + 2L * (z) + 2L * c->istride[1] * (y) + 2L * c->istride[0] * (x);                       \
+    R->a2as[2 * dst] = e_[0]; R->a2as[2 * dst + 1] = e_[1];                                                        \
+  } while (0)
+  /* loop order = destination order, as in the reference (:1038-1045 xyz, :1061-1118 xzy) */
+  if (S) {
+    for (int x = from_x; x < to_x; x++)
+      for (int y = 0; y < m2; y++)
+        for (int z = 0; z < w->Nzn; z++) PACK1_ELEM(x, y, z);
+  } else {
+    for (int x = from_x; x < to_x; x++)
+      for (int z = 0; z < w->Nzn; z++)
+        for (int y = 0; y < m2; y++) PACK1_ELEM(x, y, z);
+  }
+#undef PACK1_ELEM
+  free(own);
 }
 
 /* communicate_a2a / communicate_a2av, offt-compute.c:835-881, counts from 3512-3526 */
@@ -302,32 +318,44 @@ static void unpack1_ffty(const orc_world *w, orank *R, int tile, int myT, double
   const int F2 = c->F2, b2 = c->b2, M2 = c->M2, M3 = c->M3, M4 = c->M4, m3 = c->m3, p1 = c->p1, p2 = c->p2;
   const int ignore_Ry = (w->is_oned && p1 == 1); /* :1240 */
   double *out = R->out;
-  for (int x = from_x; x < to_x; x++)
-    for (int y = 0; y < w->Ny; y++) {
-      own_t o = owner(y, F2, b2, p2);
-      int wide = (F2 * (p2 - b2) <= y);
-      for (int z = 0; z < m3; z++) {
-        long B, src, dst;
-        if (S) { /* :1278-1311 */
-          int Sy, Sx;
-          if (is_a2av) {
-            B = wide ? (long)(p2 - b2) * (myT * F2 * m3) + (long)(o.a - (p2 - b2)) * (myT * (F2 + 1) * m3) : (long)o.a * (myT * F2 * m3);
-            Sy = m3; Sx = wide ? (F2 + 1) * m3 : F2 * m3;
-          } else { B = (long)o.a * (myT * M2 * M3); Sy = M3; Sx = M2 * M3; }
-          src = B + z + (long)(y - o.off) * Sy + (long)(x - from_x) * Sx;
-          dst = z + (long)M3 * y + (long)M3 * M4 * p1 * x;
-        } else { /* :1353-1385 */
-          int Sz, Sx;
-          if (is_a2av) {
-            B = wide ? (long)(p2 - b2) * (myT * F2 * m3) + (long)(o.a - (p2 - b2)) * (myT * (F2 + 1) * m3) : (long)o.a * (myT * F2 * m3);
-            Sz = wide ? F2 + 1 : F2; Sx = Sz * m3;
-          } else { B = (long)o.a * (myT * M2 * M3); Sz = M2; Sx = M2 * M3; }
-          src = B + (y - o.off) + (long)z * Sz + (long)(x - from_x) * Sx;
-          dst = y + (long)M4 * p1 * (z + (long)M3 * x);
-        }
-        memcpy(out + 2 * dst, R->a2ar + 2 * src, 2 * sizeof(double));
-      }
-    }
+  own_t *own = (own_t *)malloc(sizeof(own_t) * (size_t)w->Ny);
+  for (int y = 0; y < w->Ny; y++) own[y] = owner(y, F2, b2, p2);
+#define UNPACK1_ELEM(x, y, z)                                                                                      \
+  do {                                                                                                             \
+    const own_t o = own[y];                                                                                        \
+    const int wide = (F2 * (p2 - b2) <= (y));                                                                      \
+    long B, src, dst;                                                                                              \
+    if (S) { /* :1278-1311 */                                                                                      \
+      int Sy, Sx;                                                                                                  \
+      if (is_a2av) {                                                                                               \
+        B = wide ? (long)(p2 - b2) * (myT * F2 * m3) + (long)(o.a - (p2 - b2)) * (myT * (F2 + 1) * m3) : (long)o.a * (myT * F2 * m3); \
+        Sy = m3; Sx = wide ? (F2 + 1) * m3 : F2 * m3;                                                              \
+      } else { B = (long)o.a * (myT * M2 * M3); Sy = M3; Sx = M2 * M3; }                                           \
+      src = B + (z) + (long)((y) - o.off) * Sy + (long)((x) - from_x) * Sx;                                        \
+      dst = (z) + (long)M3 * (y) + (long)M3 * M4 * p1 * (x);                                                       \
+    } else { /* :1353-1385 */                                                                                      \
+      int Sz, Sx;                                                                                                  \
+      if (is_a2av) {                                                                                               \
+        B = wide ? (long)(p2 - b2) * (myT * F2 * m3) + (long)(o.a - (p2 - b2)) * (myT * (F2 + 1) * m3) : (long)o.a * (myT * F2 * m3); \
+        Sz = wide ? F2 + 1 : F2; Sx = Sz * m3;                                                                     \
+      } else { B = (long)o.a * (myT * M2 * M3); Sz = M2; Sx = M2 * M3; }                                           \
+      src = B + ((y) - o.off) + (long)(z) * Sz + (long)((x) - from_x) * Sx;                                        \
+      dst = (y) + (long)M4 * p1 * ((z) + (long)M3 * (x));                                                          \
+    }                                                                                                              \
+    out[2 * dst] = R->a2ar[2 * src]; out[2 * dst + 1] = R->a2ar[2 * src + 1];                                      \
+  } while (0)
+  /* loop order = destination order (:1269-1271 xyz, :1341-1346 xzy) */
+  if (S) {
+    for (int x = from_x; x < to_x; x++)
+      for (int y = 0; y < w->Ny; y++)
+        for (int z = 0; z < m3; z++) UNPACK1_ELEM(x, y, z);
+  } else {
+    for (int x = from_x; x < to_x; x++)
+      for (int z = 0; z < m3; z++)
+        for (int y = 0; y < w->Ny; y++) UNPACK1_ELEM(x, y, z);
+  }
+#undef UNPACK1_ELEM
+  free(own);
   /* FFTy share of phase 1, :1479-1495 */
   for (int x = from_x; x < to_x; x++)
     for (int z = 0; z < m3; z++)
@@ -401,30 +429,46 @@ static void ffty_pack2(const orc_world *w, orank *R, int tile, int myT, double *
         else if (eq) orc_fft_execute(w->py, out + 2L * M4 * p1 * (z + (long)M3 * x), 1, 0, 1, scr);          /* :1842 */
         else orc_fft_execute(w->py, out + 2L * M4 * p1 * (x + (long)M1 * z), 1, 0, 1, scr);                  /* :1989 */
       }
-  for (int x = 0; x < m1; x++)
-    for (int y = 0; y < w->Ny; y++) {
-      own_t o = owner(y, F4, b4, p1);
-      int wide = (F4 * (p1 - b4) <= y);
-      long Bv = wide ? (long)(p1 - b4) * (m1 * F4 * myT) + (long)(o.a - (p1 - b4)) * (m1 * (F4 + 1) * myT) : (long)o.a * (m1 * F4 * myT);
-      long Be = (long)o.a * (M1 * M4 * myT);
-      for (int z = from_z; z < to_z; z++) {
-        long src, dst;
-        if (S) { /* :1744-1776 */
-          long B = is_a2av ? Bv : Be; int Sy = myT, Sx = is_a2av ? myT * (wide ? F4 + 1 : F4) : myT * M4;
-          dst = B + (z - from_z) + (long)(y - o.off) * Sy + (long)x * Sx;
-          src = z + (long)M3 * y + (long)M3 * M4 * p1 * x;
-        } else if (eq) { /* block [y][z][x], :1879-1911 */
-          long B = is_a2av ? Bv : Be; int Sz = is_a2av ? m1 : M1, Sy = Sz * myT;
-          dst = B + x + (long)(z - from_z) * Sz + (long)(y - o.off) * Sy;
-          src = y + (long)w->Ny * z + (long)M4 * p1 * M3 * x; /* note Ny*z, SURVEY.md Appendix F */
-        } else { /* block [z][y][x], :2026-2058 */
-          long B = is_a2av ? Bv : Be; int Sy = is_a2av ? m1 : M1, Sz = is_a2av ? m1 * (wide ? F4 + 1 : F4) : M1 * M4;
-          dst = B + x + (long)(y - o.off) * Sy + (long)(z - from_z) * Sz;
-          src = y + (long)M4 * p1 * x + (long)M4 * p1 * M1 * z;
-        }
-        memcpy(R->a2as + 2 * dst, out + 2 * src, 2 * sizeof(double));
-      }
-    }
+  own_t *own = (own_t *)malloc(sizeof(own_t) * (size_t)w->Ny);
+  for (int y = 0; y < w->Ny; y++) own[y] = owner(y, F4, b4, p1);
+#define PACK2_ELEM(x, y, z)                                                                                        \
+  do {                                                                                                             \
+    const own_t o = own[y];                                                                                        \
+    const int wide = (F4 * (p1 - b4) <= (y));                                                                      \
+    const long Bv = wide ? (long)(p1 - b4) * (m1 * F4 * myT) + (long)(o.a - (p1 - b4)) * (m1 * (F4 + 1) * myT) : (long)o.a * (m1 * F4 * myT); \
+    const long B = is_a2av ? Bv : (long)o.a * (M1 * M4 * myT);                                                     \
+    long src, dst;                                                                                                 \
+    if (S) { /* :1744-1776 */                                                                                      \
+      const int Sy = myT, Sx = is_a2av ? myT * (wide ? F4 + 1 : F4) : myT * M4;                                    \
+      dst = B + ((z) - from_z) + (long)((y) - o.off) * Sy + (long)(x) * Sx;                                        \
+      src = (z) + (long)M3 * (y) + (long)M3 * M4 * p1 * (x);                                                       \
+    } else if (eq) { /* block [y][z][x], :1879-1911 */                                                             \
+      const int Sz = is_a2av ? m1 : M1, Sy = Sz * myT;                                                             \
+      dst = B + (x) + (long)((z) - from_z) * Sz + (long)((y) - o.off) * Sy;                                        \
+      src = (y) + (long)w->Ny * (z) + (long)M4 * p1 * M3 * (x); /* note Ny*z, SURVEY.md Appendix F */              \
+    } else { /* block [z][y][x], :2026-2058 */                                                                     \
+      const int Sy = is_a2av ? m1 : M1, Sz = is_a2av ? m1 * (wide ? F4 + 1 : F4) : M1 * M4;                        \
+      dst = B + (x) + (long)((y) - o.off) * Sy + (long)((z) - from_z) * Sz;                                        \
+      src = (y) + (long)M4 * p1 * (x) + (long)M4 * p1 * M1 * (z);                                                  \
+    }                                                                                                              \
+    R->a2as[2 * dst] = out[2 * src]; R->a2as[2 * dst + 1] = out[2 * src + 1];                                      \
+  } while (0)
+  /* loop order = destination order (:1735-1737 xyz, :1870-1872 yzx, :2016-2020 zyx) */
+  if (S) {
+    for (int x = 0; x < m1; x++)
+      for (int y = 0; y < w->Ny; y++)
+        for (int z = from_z; z < to_z; z++) PACK2_ELEM(x, y, z);
+  } else if (eq) {
+    for (int y = 0; y < w->Ny; y++)
+      for (int z = from_z; z < to_z; z++)
+        for (int x = 0; x < m1; x++) PACK2_ELEM(x, y, z);
+  } else {
+    for (int z = from_z; z < to_z; z++)
+      for (int y = 0; y < w->Ny; y++)
+        for (int x = 0; x < m1; x++) PACK2_ELEM(x, y, z);
+  }
+#undef PACK2_ELEM
+  free(own);
 }
 
 static void a2a_phase2(orc_world *w, int rank_y, int myT) { /* counts :3693-3707 */
@@ -454,30 +498,46 @@ static void unpack2_fftx(const orc_world *w, orank *R, int tile, int myT, double
   const int F1 = c->F1, b1 = c->b1, M1 = c->M1, M3 = c->M3, M4 = c->M4, m4 = c->m4, p1 = c->p1;
   const int eq = (w->is_equalxy && M1 == M4);
   double *out = R->out;
-  for (int x = 0; x < w->Nx; x++) {
-    own_t o = owner(x, F1, b1, p1);
-    int wide = (F1 * (p1 - b1) <= x);
-    long Bv = wide ? (long)(p1 - b1) * (F1 * m4 * myT) + (long)(o.a - (p1 - b1)) * ((F1 + 1) * m4 * myT) : (long)o.a * (F1 * m4 * myT);
-    long Be = (long)o.a * (M1 * M4 * myT);
+  own_t *own = (own_t *)malloc(sizeof(own_t) * (size_t)w->Nx);
+  for (int x = 0; x < w->Nx; x++) own[x] = owner(x, F1, b1, p1);
+#define UNPACK2_ELEM(x, y, z)                                                                                      \
+  do {                                                                                                             \
+    const own_t o = own[x];                                                                                        \
+    const int wide = (F1 * (p1 - b1) <= (x));                                                                      \
+    const long Bv = wide ? (long)(p1 - b1) * (F1 * m4 * myT) + (long)(o.a - (p1 - b1)) * ((F1 + 1) * m4 * myT) : (long)o.a * (F1 * m4 * myT); \
+    const long B = is_a2av ? Bv : (long)o.a * (M1 * M4 * myT);                                                     \
+    long src, dst;                                                                                                 \
+    if (S) { /* :2418-2450 */                                                                                      \
+      const int Sy = myT, Sx = is_a2av ? myT * m4 : myT * M4;                                                      \
+      src = B + ((z) - from_z) + (long)(y) * Sy + (long)((x) - o.off) * Sx;                                        \
+      dst = (z) + (long)M3 * (y) + (long)M3 * M4 * (x);                                                            \
+    } else if (eq) { /* :2538-2570 */                                                                              \
+      const int Sz = is_a2av ? (wide ? F1 + 1 : F1) : M1, Sy = Sz * myT;                                           \
+      src = B + ((x) - o.off) + (long)((z) - from_z) * Sz + (long)(y) * Sy;                                        \
+      dst = (x) + (long)M1 * p1 * ((z) + (long)M3 * (y));                                                          \
+    } else { /* :2655-2687 */                                                                                      \
+      const int Sy = is_a2av ? (wide ? F1 + 1 : F1) : M1, Sz = is_a2av ? Sy * m4 : M1 * M4;                        \
+      src = B + ((x) - o.off) + (long)(y) * Sy + (long)((z) - from_z) * Sz;                                        \
+      dst = (x) + (long)M1 * p1 * ((y) + (long)M4 * (z));                                                          \
+    }                                                                                                              \
+    out[2 * dst] = R->a2ar[2 * src]; out[2 * dst + 1] = R->a2ar[2 * src + 1];                                      \
+  } while (0)
+  /* loop order = destination order (:2409-2411 xyz, :2528-2532 yzx, :2645-2649 zyx) */
+  if (S) {
+    for (int x = 0; x < w->Nx; x++)
+      for (int y = 0; y < m4; y++)
+        for (int z = from_z; z < to_z; z++) UNPACK2_ELEM(x, y, z);
+  } else if (eq) {
     for (int y = 0; y < m4; y++)
-      for (int z = from_z; z < to_z; z++) {
-        long src, dst;
-        if (S) { /* :2418-2450 */
-          long B = is_a2av ? Bv : Be; int Sy = myT, Sx = is_a2av ? myT * m4 : myT * M4;
-          src = B + (z - from_z) + (long)y * Sy + (long)(x - o.off) * Sx;
-          dst = z + (long)M3 * y + (long)M3 * M4 * x;
-        } else if (eq) { /* :2538-2570 */
-          long B = is_a2av ? Bv : Be; int Sz = is_a2av ? (wide ? F1 + 1 : F1) : M1, Sy = Sz * myT;
-          src = B + (x - o.off) + (long)(z - from_z) * Sz + (long)y * Sy;
-          dst = x + (long)M1 * p1 * (z + (long)M3 * y);
-        } else { /* :2655-2687 */
-          long B = is_a2av ? Bv : Be; int Sy = is_a2av ? (wide ? F1 + 1 : F1) : M1, Sz = is_a2av ? Sy * m4 : M1 * M4;
-          src = B + (x - o.off) + (long)y * Sy + (long)(z - from_z) * Sz;
-          dst = x + (long)M1 * p1 * (y + (long)M4 * z);
-        }
-        memcpy(out + 2 * dst, R->a2ar + 2 * src, 2 * sizeof(double));
-      }
+      for (int z = from_z; z < to_z; z++)
+        for (int x = 0; x < w->Nx; x++) UNPACK2_ELEM(x, y, z);
+  } else {
+    for (int z = from_z; z < to_z; z++)
+      for (int y = 0; y < m4; y++)
+        for (int x = 0; x < w->Nx; x++) UNPACK2_ELEM(x, y, z);
   }
+#undef UNPACK2_ELEM
+  free(own);
   for (int y = 0; y < m4; y++)
     for (int z = from_z; z < to_z; z++) {
       if (S) orc_fft_execute(w->px, out + 2L * z + 2L * M3 * y, (long)M3 * M4, 0, 1, scr);                 /* :2493-2495 */
