@@ -15,8 +15,11 @@ all: offt_amd/liboffthip.so oracle/liboracle.so
 $(BUILD):
 	mkdir -p $(BUILD)
 
-$(BUILD)/offt_kernels.o: $(CSRC)/offt_kernels.hip $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h | $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/kernel_resource_usage.txt || (cat $(BUILD)/kernel_resource_usage.txt; false)
+# the kernel instantiations are grouped into several translation units so that `make -j` compiles them in parallel
+HIPSRC    := offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f32 offt_reg_mixed_f64_a offt_reg_mixed_f64_b offt_reg_mixed_f32
+HIPOBJ    := $(HIPSRC:%=$(BUILD)/%.o)
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/offt_panel.hpp $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h $(CSRC)/offt_wr_consts.h | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/$*.resource_usage.txt || (cat $(BUILD)/$*.resource_usage.txt; false)
 
 $(BUILD)/offt_host.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backend.h include/offt.h include/offt_hip.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
@@ -24,7 +27,7 @@ $(BUILD)/offt_host.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backe
 # The HIP runtime is deliberately NOT a DT_NEEDED entry: the hosting process
 # decides which libamdhip64 is in use (PyTorch bundles its own); C programs link
 # -lamdhip64 themselves.
-offt_amd/liboffthip.so: $(BUILD)/offt_kernels.o $(BUILD)/offt_host.o
+offt_amd/liboffthip.so: $(HIPOBJ) $(BUILD)/offt_host.o
 	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lm -lpthread
 
 oracle/liboracle.so: oracle/oracle_fft.c oracle/oracle_offt.c oracle/oracle.h
@@ -52,10 +55,10 @@ else
 endif
 
 # host logic under AddressSanitizer + UBSan on the CPU test backend (GPU ASan is not available on the pool)
-asan-test: $(BUILD)/offt_kernels.o
+asan-test: $(HIPOBJ)
 	mkdir -p $(BUILD)/asan
 	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude -c $(CSRC)/offt_host.c -o $(BUILD)/asan/offt_host.o
-	g++ -shared -fsanitize=address,undefined -o $(BUILD)/asan/liboffthip.so $(BUILD)/offt_kernels.o $(BUILD)/asan/offt_host.o -Wl,--allow-shlib-undefined -ldl -lm -lpthread
+	g++ -shared -fsanitize=address,undefined -o $(BUILD)/asan/liboffthip.so $(HIPOBJ) $(BUILD)/asan/offt_host.o -Wl,--allow-shlib-undefined -ldl -lm -lpthread
 	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fPIC -shared -Ioracle -I$(CSRC) -o $(BUILD)/asan/libcpubackend.so tests/cpu_backend.c oracle/oracle_fft.c -lm
 	cp tests/libcpubackend.so $(BUILD)/asan/libcpubackend.so.orig
 	cp $(BUILD)/asan/libcpubackend.so tests/libcpubackend.so

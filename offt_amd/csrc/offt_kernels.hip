@@ -1,4 +1,5 @@
-// offt_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the OFFT hot path.
+// offt_kernels.hip -- C ABI (offt_hipk.h), kernel registry, twiddle tables and launchers of the
+// hand-written CDNA4 (gfx950) kernels; the panel kernels themselves are in offt_panel.hpp.
 //
 // What the reference does per pencil with FFTW + element-wise memcpy
 // (offt-compute.c:959-963 FFTz, 1484-1494 / 1708-1710 FFTy, 2493-2495 FFTx,
@@ -33,9 +34,17 @@
 #include <cstring>
 #include <cstdlib>
 #include "offt_hipk.h"
-#include "offt_w32_consts.h"
+#include "offt_panel.hpp"
+
+namespace offtk {
+std::vector<Variant> &registry() {
+  static std::vector<Variant> r;
+  return r;
+}
+}  // namespace offtk
 
 namespace {
+using namespace offtk;
 
 thread_local char g_err[512] = "";
 #define HIPK_CHECK(call)                                                          \
@@ -47,319 +56,6 @@ thread_local char g_err[512] = "";
       return -1;                                                                  \
     }                                                                             \
   } while (0)
-
-template <typename T> struct vec2;
-template <> struct vec2<double> { using type = double2; };
-template <> struct vec2<float> { using type = float2; };
-
-template <typename T> struct cx { T x, y; };
-
-// global memory access helpers: 16-B (f64) / 8-B (f32) per lane.  Every element is
-// touched exactly once per pass, so loads and stores are non-temporal (streaming): A/B on
-// 1024^3 (profiles/r01_sweep.txt): -6 % transform time vs default cache policy.
-// -DOFFT_NO_NT_LOAD / -DOFFT_NO_NT_STORE restore the default policy for A/B builds.
-template <typename V2>
-__device__ __forceinline__ V2 gload(const V2 *p) {
-#ifndef OFFT_NO_NT_LOAD
-  using E = decltype(p->x);
-  typedef E vt __attribute__((ext_vector_type(2)));
-  vt r = __builtin_nontemporal_load(reinterpret_cast<const vt *>(p));
-  V2 o; o.x = r.x; o.y = r.y; return o;
-#else
-  return *p;
-#endif
-}
-template <typename V2>
-__device__ __forceinline__ void gstore(V2 *p, V2 v) {
-#ifndef OFFT_NO_NT_STORE
-  using E = decltype(p->x);
-  typedef E vt __attribute__((ext_vector_type(2)));
-  vt r; r.x = v.x; r.y = v.y;
-  __builtin_nontemporal_store(r, reinterpret_cast<vt *>(p));
-#else
-  *p = v;
-#endif
-}
-
-template <int B, int E_, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (B < E_) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E_>(f);
-  }
-}
-
-constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
-constexpr int bitrev(int v, int bits) {
-  int r = 0;
-  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
-  return r;
-}
-
-constexpr double W32C[32] = OFFT_W32_COS;
-constexpr double W32S[32] = OFFT_W32_SIN;
-
-// d * w32^K, w32 = exp(-2 pi i / 32)
-template <typename T, int K>
-__device__ __forceinline__ cx<T> mulw32(cx<T> d) {
-  constexpr int k = K & 31;
-  if constexpr (k == 0) return d;
-  else if constexpr (k == 8) return cx<T>{d.y, -d.x};
-  else if constexpr (k == 16) return cx<T>{-d.x, -d.y};
-  else if constexpr (k == 24) return cx<T>{-d.y, d.x};
-  else if constexpr (k == 4) {
-    constexpr T s = (T)W32C[4];
-    return cx<T>{(d.x + d.y) * s, (d.y - d.x) * s};
-  } else if constexpr (k == 12) {
-    constexpr T s = (T)W32C[4];
-    return cx<T>{(d.y - d.x) * s, -(d.x + d.y) * s};
-  } else {
-    constexpr T c = (T)W32C[k], s = (T)W32S[k];
-    return cx<T>{d.x * c + d.y * s, d.y * c - d.x * s};
-  }
-}
-
-// In-register radix-R DFT (R = 2..32), radix-2 decimation in frequency with
-// compile-time twiddles.  Result is left in bit-reversed order:
-// X[k] = v[bitrev(k)].
-template <typename T, int R>
-__device__ __forceinline__ void dft_reg(cx<T> *v) {
-  static_for<0, ilog2(R)>([&](auto st) {
-    constexpr int h = R >> (decltype(st)::value + 1);
-    static_for<0, R / 2>([&](auto bi) {
-      constexpr int b = (decltype(bi)::value / h) * 2 * h;
-      constexpr int i = decltype(bi)::value % h;
-      cx<T> p = v[b + i], q = v[b + i + h];
-      v[b + i] = cx<T>{p.x + q.x, p.y + q.y};
-      cx<T> d{p.x - q.x, p.y - q.y};
-      v[b + i + h] = mulw32<T, i * (16 / h)>(d);
-    });
-  });
-}
-
-struct PassArgs {
-  long long in_axis, in_col, in_b1, in_b2, in_blk;
-  long long out_axis, out_col, out_b1, out_b2, out_blk;
-  int in_shift, out_shift;  // log2(split) or 31 for "no split"
-  int ncols, ncp, nb1;      // ncp = column panels per batch entry
-  int conj;                 // 1: inverse transform via conj-in / conj-out
-  double scale;
-};
-
-template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
-struct PanelCfg {
-  static constexpr int TPL = N / E;
-  static constexpr int NT = TPL * COLS;
-  static constexpr int NSTAGE = (R2 > 1) ? 3 : ((R1 > 1) ? 2 : 1);
-  // LDS image of one column: Stockham stage s writes index (q-k)*R + k + t*Ns with lanes
-  // along q and reads index q' + t'*(N/R') with lanes along q'.  Stage 0 (Ns = 1) is a
-  // stride-R0 write: all lanes of a ds_write group would hit one bank.
-  //  * R0 >= 16: XOR swizzle  i -> i ^ ((i >> log2 R0) & 15).  The strided writes spread
-  //    over 16 bank pairs, and the unit-stride accesses are only permuted inside aligned
-  //    16-element runs, so they stay conflict-free (a padded image misaligns them: the
-  //    PMC pass showed SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE with padding).
-  //  * R0 < 16 (small N): pad one element every R0.
-  static constexpr bool SWZ = (R0 >= 16);
-  static constexpr int PADSHIFT = ilog2(R0) < 3 ? 3 : ilog2(R0);
-  static constexpr int SWZSHIFT = ilog2(R0);
-  static constexpr int NPAD = SWZ ? N : N + (N >> PADSHIFT);
-  // column pitch == 4 (mod 32) elements: the 8 columns x 4 rows of one 32-lane ds_read_b64
-  // group of a strided-store flavour land in 32 distinct bank pairs
-  static constexpr int LSTRIDE = SWZ ? ((NPAD + 31) / 32) * 32 + 4 : ((NPAD + 13) / 16) * 16 + 2;
-  static constexpr int QT = (N >= 4) ? N / 4 + 1 : 1;
-  static constexpr size_t EX_BYTES =
-      NSTAGE > 1 ? (size_t)COLS * LSTRIDE * sizeof(T) * (SPLIT ? 1 : 2) : 0;
-  static constexpr size_t TW_OFF = (EX_BYTES + 15) / 16 * 16;
-  static constexpr size_t LDS_BYTES = NSTAGE > 1 ? TW_OFF + (size_t)QT * 2 * sizeof(T) : 0;
-  // occupancy target handed to __launch_bounds__ (2nd argument = waves per
-  // SIMD): as many workgroups per CU as the 160 KiB LDS admits, at most 4
-  // waves per SIMD -- enough to overlap one group's butterflies with another
-  // group's HBM traffic without starving the register allocator.
-  static constexpr int WG_PER_CU_LDS = LDS_BYTES ? (int)(160 * 1024 / LDS_BYTES) : 8;
-  static constexpr int WPS_RAW = (WG_PER_CU_LDS * NT + 255) / 256;
-  static constexpr int WPS = WPS_RAW < 1 ? 1 : (WPS_RAW > 4 ? 4 : WPS_RAW);
-  // register budget: an E-point thread keeps E*sizeof(T)/2 data VGPRs; it needs
-  // roughly twice that (butterfly temporaries, addresses, exchange staging)
-  static constexpr int DATA_VGPR = E * (int)sizeof(T) / 2;
-  // (a radix-32 butterfly alone keeps ~40 temporaries alive: never ask for more than 2 waves/SIMD)
-  static constexpr int WPS_REG = (DATA_VGPR >= 128 || R0 >= 32 || R1 >= 32 || R2 >= 32) ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
-  static constexpr int WPS_MIN = (NT + 255) / 256;  // one workgroup must fit on a CU
-  static constexpr int WPS_E = WPS < WPS_REG ? WPS : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
-};
-
-template <bool SWZ, int SHIFT>
-__device__ __forceinline__ int padidx(int i) {
-  if constexpr (SWZ) return i ^ ((i >> SHIFT) & 15);
-  else return i + (i >> SHIFT);
-}
-
-template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
-__global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
-fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
-            const typename vec2<T>::type *twq) {
-  using V2 = typename vec2<T>::type;
-  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
-  constexpr int TPL = Cfg::TPL, NT = Cfg::NT, NSTAGE = Cfg::NSTAGE;
-  constexpr int LSTRIDE = Cfg::LSTRIDE;
-  constexpr bool SWZ = Cfg::SWZ;
-  constexpr int PS = SWZ ? Cfg::SWZSHIFT : Cfg::PADSHIFT;
-  static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
-  static_assert(E % R0 == 0 && E % R1 == 0 && E % R2 == 0 && N % E == 0, "bad E");
-
-  extern __shared__ __align__(16) unsigned char smem[];
-  T *exs = reinterpret_cast<T *>(smem);
-  V2 *exv = reinterpret_cast<V2 *>(smem);
-  V2 *tw = reinterpret_cast<V2 *>(smem + Cfg::TW_OFF);
-
-  const int tid = threadIdx.x;
-  if constexpr (NSTAGE > 1) {
-    for (int i = tid; i < Cfg::QT; i += NT) tw[i] = twq[i];
-  }
-
-  // panel -> (column panel, b1, b2)
-  const unsigned bid = blockIdx.x;
-  const int cp = bid % (unsigned)a.ncp;
-  const unsigned rest = bid / (unsigned)a.ncp;
-  const int b1 = rest % (unsigned)a.nb1;
-  const int b2 = rest / (unsigned)a.nb1;
-  const int c0 = cp * COLS;
-
-  cx<T> v[E];
-
-  // ---------------- stage 0: global load -------------------------------------
-  int c, j;
-  if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
-  else               { c = tid % COLS; j = tid / COLS; }
-  {
-    const bool valid = (c0 + c) < a.ncols;
-    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
-    const int mask = (int)((1u << a.in_shift) - 1u);
-    static_for<0, E>([&](auto ii) {
-      constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
-      const int n = j + u * TPL + t * (N / R0);
-      V2 val;
-      val.x = 0; val.y = 0;
-      if constexpr (R2C) {
-        // n real values at the head of the row: element n is the n-th T of the row
-        if (valid) val.x = reinterpret_cast<const T *>(src)[n];
-        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
-      } else {
-        if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
-        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
-      }
-    });
-  }
-
-  // ---------------- stages ---------------------------------------------------
-  static_for<0, NSTAGE>([&](auto sidx) {
-    constexpr int s = decltype(sidx)::value;
-    constexpr int R = (s == 0) ? R0 : ((s == 1) ? R1 : R2);
-    constexpr int Ns = (s == 0) ? 1 : ((s == 1) ? R0 : R0 * R1);
-    constexpr int NB = E / R;           // butterflies per thread
-    constexpr int LR = ilog2(R);
-
-    if constexpr (s > 0) {
-      // inter-stage twiddles w_N^(k * t * N/(Ns*R)), k = q mod Ns
-      constexpr int M = N / (Ns * R);
-      static_for<0, NB>([&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        const int q = j + u * TPL;
-        const int km = (q & (Ns - 1)) * M;
-        static_for<1, R>([&](auto tt) {
-          constexpr int t = decltype(tt)::value;
-          const int e = km * t;
-          const int qd = e / (N / 4);
-          const int r = e & (N / 4 - 1);
-          V2 w = tw[r];
-          T wr = w.x, wi = w.y;
-          // multiply by (-i)^qd
-          T cr = (qd & 1) ? wi : wr;
-          T ci = (qd & 1) ? -wr : wi;
-          if (qd & 2) { cr = -cr; ci = -ci; }
-          cx<T> x = v[u * R + t];
-          v[u * R + t] = cx<T>{x.x * cr - x.y * ci, x.x * ci + x.y * cr};
-        });
-      });
-    }
-
-    static_for<0, NB>([&](auto uu) { dft_reg<T, R>(&v[decltype(uu)::value * R]); });
-
-    if constexpr (s < NSTAGE - 1) {
-      // ---- exchange through LDS: write Stockham-ordered, read strided --------
-      constexpr int Rn = (s == 0) ? R1 : R2;      // next radix
-      constexpr bool next_last = (s + 1 == NSTAGE - 1);
-      int cn, jn;                                  // reader mapping
-      if constexpr (next_last && !OUTC) { cn = tid % COLS; jn = tid / COLS; }
-      else                              { jn = tid % TPL; cn = tid / TPL; }
-
-      auto wr_idx = [&](int u, int t) {
-        const int q = j + u * TPL;
-        const int k = q & (Ns - 1);
-        return c * LSTRIDE + padidx<SWZ, PS>((q - k) * R + k + t * Ns);
-      };
-      auto rd_idx = [&](int u, int t) {
-        return cn * LSTRIDE + padidx<SWZ, PS>(jn + u * TPL + t * (N / Rn));
-      };
-
-      // (the twiddle table written at kernel entry becomes visible at the first
-      //  barrier below, before any stage-1 lookup)
-      if constexpr (s > 0) __syncthreads();  // previous exchange's reads done
-      if constexpr (SPLIT) {
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-          exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].x;
-        });
-        __syncthreads();
-        T re[E];
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
-          re[decltype(ii)::value] = exs[rd_idx(u, t)];
-        });
-        __syncthreads();
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-          exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].y;
-        });
-        __syncthreads();
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
-          v[decltype(ii)::value] = cx<T>{re[decltype(ii)::value], exs[rd_idx(u, t)]};
-        });
-      } else {
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-          cx<T> x = v[u * R + bitrev(t, LR)];
-          V2 w; w.x = x.x; w.y = x.y;
-          exv[wr_idx(u, t)] = w;
-        });
-        __syncthreads();
-        static_for<0, E>([&](auto ii) {
-          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
-          V2 w = exv[rd_idx(u, t)];
-          v[decltype(ii)::value] = cx<T>{w.x, w.y};
-        });
-      }
-      c = cn; j = jn;
-    } else {
-      // ---------------- last stage: global store ------------------------------
-      const bool valid = (c0 + c) < a.ncols;
-      V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
-      const int mask = (int)((1u << a.out_shift) - 1u);
-      const T sc = (T)a.scale;
-      static_for<0, E>([&](auto ii) {
-        constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-        const int n = j + u * TPL + t * (N / R);
-        cx<T> x = v[u * R + bitrev(t, LR)];
-        V2 w;
-        w.x = x.x * sc;
-        w.y = (a.conj ? -x.y : x.y) * sc;
-        if (valid && (!R2C || n <= N / 2))
-          gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
-      });
-    }
-  });
-}
-
 // ---------------------------------------------------------------------------
 // Any-length kernel: mixed-radix Stockham in LDS with run-time radices.
 // It exists so that every length the reference accepts (FFTW takes any N) is
@@ -371,9 +67,11 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 // output of one radix-r butterfly:
 //   y[(q-k) r + k + j Ns] = sum_t x[q + t N/r] * w_N^(k t M) * w_r^(j t),
 //   k = q mod Ns, M = N / (Ns r)
-// i.e. r complex multiply-adds with exact table twiddles w_N^m (m = 0..N-1,
-// staged in LDS when it fits).  Cost N * sum(r_s) per line instead of N^2; a
-// prime N degenerates to one stage of radix N (the plain DFT).
+// with exact table twiddles w_N^m (m = 0..N-1, staged in LDS when it fits).
+// Radices 2, 3, 4, 5 are done as whole butterflies (r loads, r-1 twiddles, a
+// constant-coefficient DFT, r stores); any other prime radix produces one
+// output per work item with r multiply-adds, so a line costs at most
+// N * sum(r_s) instead of N^2 and a prime N degenerates to the plain DFT.
 // Also handles the reference's uneven A2AV per-peer splits on either side and
 // the real-input z pass.
 // ---------------------------------------------------------------------------
@@ -406,8 +104,63 @@ __device__ __forceinline__ long long split_off(int k, int split, int nfloor, lon
   return (long long)a * blk + (long long)r * axis;
 }
 
+// one radix-R butterfly of the any-length kernel: inputs xin[t * is], t = 0..R-1, twiddled by
+// w_N^(kM t) from the table, outputs yout[j * os]
+template <typename T, int R>
+__device__ __forceinline__ void mixed_butterfly(const typename vec2<T>::type *xin, typename vec2<T>::type *yout,
+                                                int is, int os, int kM, const typename vec2<T>::type *tw) {
+  using V2 = typename vec2<T>::type;
+  cx<T> v[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    const V2 a = xin[t * is];
+    if (t == 0) { v[0] = cx<T>{a.x, a.y}; }
+    else {
+      const V2 w = tw[kM * t];
+      v[t] = cx<T>{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+    }
+  }
+  cx<T> o[R];
+  if constexpr (R == 2) {
+    o[0] = cx<T>{v[0].x + v[1].x, v[0].y + v[1].y};
+    o[1] = cx<T>{v[0].x - v[1].x, v[0].y - v[1].y};
+  } else if constexpr (R == 3) {
+    constexpr T S3 = (T)0.86602540378443864676;  // sin(2 pi / 3)
+    const cx<T> s{v[1].x + v[2].x, v[1].y + v[2].y}, d{v[1].x - v[2].x, v[1].y - v[2].y};
+    const cx<T> t{v[0].x - (T)0.5 * s.x, v[0].y - (T)0.5 * s.y};
+    const cx<T> e{S3 * d.y, -S3 * d.x};  // -i * S3 * d
+    o[0] = cx<T>{v[0].x + s.x, v[0].y + s.y};
+    o[1] = cx<T>{t.x + e.x, t.y + e.y};
+    o[2] = cx<T>{t.x - e.x, t.y - e.y};
+  } else if constexpr (R == 4) {
+    const cx<T> a{v[0].x + v[2].x, v[0].y + v[2].y}, b{v[0].x - v[2].x, v[0].y - v[2].y};
+    const cx<T> c{v[1].x + v[3].x, v[1].y + v[3].y}, d{v[1].x - v[3].x, v[1].y - v[3].y};
+    o[0] = cx<T>{a.x + c.x, a.y + c.y};
+    o[2] = cx<T>{a.x - c.x, a.y - c.y};
+    o[1] = cx<T>{b.x + d.y, b.y - d.x};  // b - i d
+    o[3] = cx<T>{b.x - d.y, b.y + d.x};  // b + i d
+  } else {
+    static_assert(R == 5, "radix");
+    constexpr T C1 = (T)0.30901699437494742410, C2 = (T)-0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+    constexpr T S1 = (T)0.95105651629515357212, S2 = (T)0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+    const cx<T> s1{v[1].x + v[4].x, v[1].y + v[4].y}, s2{v[2].x + v[3].x, v[2].y + v[3].y};
+    const cx<T> d1{v[1].x - v[4].x, v[1].y - v[4].y}, d2{v[2].x - v[3].x, v[2].y - v[3].y};
+    const cx<T> p1{v[0].x + C1 * s1.x + C2 * s2.x, v[0].y + C1 * s1.y + C2 * s2.y};
+    const cx<T> p2{v[0].x + C2 * s1.x + C1 * s2.x, v[0].y + C2 * s1.y + C1 * s2.y};
+    const cx<T> q1{S1 * d1.x + S2 * d2.x, S1 * d1.y + S2 * d2.y};
+    const cx<T> q2{S2 * d1.x - S1 * d2.x, S2 * d1.y - S1 * d2.y};
+    o[0] = cx<T>{v[0].x + s1.x + s2.x, v[0].y + s1.y + s2.y};
+    o[1] = cx<T>{p1.x + q1.y, p1.y - q1.x};  // p1 - i q1
+    o[4] = cx<T>{p1.x - q1.y, p1.y + q1.x};
+    o[2] = cx<T>{p2.x + q2.y, p2.y - q2.x};
+    o[3] = cx<T>{p2.x - q2.y, p2.y + q2.x};
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) { V2 w; w.x = o[j].x; w.y = o[j].y; yout[j * os] = w; }
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
             const typename vec2<T>::type *twf) {
   using V2 = typename vec2<T>::type;
@@ -430,9 +183,10 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
 
   if (a.tw_in_lds)
     for (int i = tid; i < N; i += NT) twl[i] = twf[i];
+  const float invN = 1.0f / (float)N, invnc = 1.0f / (float)nc;
   for (int i = tid; i < nc * N; i += NT) {
     int c, n;
-    if (a.in_contig) { n = i % N; c = i / N; } else { c = i % nc; n = i / nc; }
+    if (a.in_contig) { c = fdiv(i, N, invN); n = i - c * N; } else { n = fdiv(i, nc, invnc); c = i - n * nc; }
     const V2 *src = in + ibase + (long long)(c0 + c) * a.in_col;
     V2 x;
     if (a.real_in) { x.x = reinterpret_cast<const T *>(src)[n]; x.y = 0; }
@@ -448,29 +202,44 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
     const int r = a.fac[s];
     const int nq = N / r;        // butterflies per line
     const int M = N / (Ns * r);  // twiddle step
-    for (int i = tid; i < nc * N; i += NT) {
-      const int c = i / N;
-      const int o = i - c * N;   // (q, j) of this output
-      const int q = o % nq, j = o / nq;
-      const int k = q % Ns;
-      const V2 *xc = x + c * N + q;
-      T sr = 0, si = 0;
-      int e1 = 0;                // k * t * M       (< N)
-      int jt = 0;                // (j * t) mod r
-      const int kM = k * M;
-      for (int t = 0; t < r; ++t) {
-        int e = e1 + jt * nq;    // + (N/r) * ((j t) mod r)
-        if (e >= N) e -= N;
-        const V2 w = tw[e];
-        const V2 v = xc[t * nq];
-        sr += v.x * w.x - v.y * w.y;
-        si += v.x * w.y + v.y * w.x;
-        e1 += kM;
-        jt += j;
-        if (jt >= r) jt -= r;
+    if (r <= 5) {
+      // whole radix-2/3/4/5 butterflies: r loads, r-1 table twiddles, constant-coefficient DFT, r stores
+      const float invnq = 1.0f / (float)nq, invNs = 1.0f / (float)Ns;
+      for (int i = tid; i < nc * nq; i += NT) {
+        const int c = fdiv(i, nq, invnq), q = i - c * nq, k = q - fdiv(q, Ns, invNs) * Ns;
+        switch (r) {
+          case 2: mixed_butterfly<T, 2>(x + c * N + q, y + c * N + (q - k) * 2 + k, nq, Ns, k * M, tw); break;
+          case 3: mixed_butterfly<T, 3>(x + c * N + q, y + c * N + (q - k) * 3 + k, nq, Ns, k * M, tw); break;
+          case 4: mixed_butterfly<T, 4>(x + c * N + q, y + c * N + (q - k) * 4 + k, nq, Ns, k * M, tw); break;
+          default: mixed_butterfly<T, 5>(x + c * N + q, y + c * N + (q - k) * 5 + k, nq, Ns, k * M, tw); break;
+        }
       }
-      V2 res; res.x = sr; res.y = si;
-      y[c * N + (q - k) * r + k + j * Ns] = res;
+    } else {
+      // any other (prime) radix: one output per work item, r multiply-adds
+      for (int i = tid; i < nc * N; i += NT) {
+        const int c = i / N;
+        const int o = i - c * N;   // (q, j) of this output
+        const int q = o % nq, j = o / nq;
+        const int k = q % Ns;
+        const V2 *xc = x + c * N + q;
+        T sr = 0, si = 0;
+        int e1 = 0;                // k * t * M       (< N)
+        int jt = 0;                // (j * t) mod r
+        const int kM = k * M;
+        for (int t = 0; t < r; ++t) {
+          int e = e1 + jt * nq;    // + (N/r) * ((j t) mod r)
+          if (e >= N) e -= N;
+          const V2 w = tw[e];
+          const V2 v = xc[t * nq];
+          sr += v.x * w.x - v.y * w.y;
+          si += v.x * w.y + v.y * w.x;
+          e1 += kM;
+          jt += j;
+          if (jt >= r) jt -= r;
+        }
+        V2 res; res.x = sr; res.y = si;
+        y[c * N + (q - k) * r + k + j * Ns] = res;
+      }
     }
     __syncthreads();
     V2 *tmp = x; x = y; y = tmp;
@@ -478,9 +247,10 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
   }
 
   const int kend = a.real_in ? N / 2 + 1 : N;
+  const float invkend = 1.0f / (float)kend;
   for (int i = tid; i < nc * kend; i += NT) {
     int c, k;
-    if (a.out_contig) { k = i % kend; c = i / kend; } else { c = i % nc; k = i / nc; }
+    if (a.out_contig) { c = fdiv(i, kend, invkend); k = i - c * kend; } else { k = fdiv(i, nc, invnc); c = i - k * nc; }
     V2 v = x[c * N + k];
     V2 w;
     w.x = v.x * (T)a.scale;
@@ -553,119 +323,18 @@ fill_real_k(T *buf, int kind, int n0, int n1, int n2, int s0, int s1, int s2, lo
 }
 
 // ---------------------------------------------------------------------------
-// host side: kernel registry, twiddle tables, launchers
+// host side: kernel registry lookup, twiddle tables, launchers
 // ---------------------------------------------------------------------------
-struct Variant {
-  int n, prec;
-  bool inc, outc;
-  int id;
-  bool is_default;  // default for this (n, prec, inc, outc) flavour
-  bool r2c;         // real-input z-pass instantiation
-  int cols, threads, e;
-  size_t lds;
-  const void *fn;
-  std::string name;
-  bool attr_set;
-};
-
-std::vector<Variant> &registry() {
-  static std::vector<Variant> r;
-  return r;
-}
-
-// flavour bits for `defmask`: which (in_contig, out_contig) kernels use this variant by default
-enum { F_CC = 1, F_SS = 2, F_CS = 4, F_SC = 8, F_ALL = 15 };
-
-template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
-void reg_variant(int id, int defmask = -1) {
-  if (defmask < 0) defmask = id == 0 ? F_ALL : 0;
-  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
-  const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
-  char nm[160];
-  snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
-           R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
-  auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
-    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false});
-  };
-  add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
-  add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
-  add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
-  add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
-  // real-input z pass: only the contiguous-read flavours of the default variant need it
-  if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
-  if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
-}
-
 std::once_flag g_reg_once;
 void build_registry() {
-  // variant 0 of every length is the default; higher ids are the static sweep
-  // (LDS tile width x radix order x re/im split), see DESIGN.md section 5.
-#ifdef OFFT_DEV_ONLY_1024  /* developer switch: compile just the 1024 kernels for quick iteration */
-  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
-#ifdef OFFT_DEV_F32
-  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
-  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
-  reg_variant<float, 1024, 32, 32, 32, 1, 16, false>(2, 0);
-  reg_variant<float, 1024, 16, 16, 16, 4, 16, true>(3, 0);
-  reg_variant<float, 1024, 16, 16, 16, 4, 16, false>(4, 0);
-  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0);
-  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, 0);
-  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, 0);
-  reg_variant<float, 2048, 32, 32, 32, 2, 8, false>(3, 0);
-  reg_variant<float, 2048, 32, 16, 16, 8, 4, false>(4, 0);
-#endif
-#ifdef OFFT_DEV_EXTRA
-  reg_variant<double, 1024, 16, 4, 16, 16, 8, true>(2, 0);
-  reg_variant<double, 1024, 16, 16, 4, 16, 8, true>(3, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 16, true>(4, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 4, true>(5, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 8, false>(6, 0);
-  reg_variant<double, 1024, 32, 32, 32, 1, 16, true>(7, 0);
-#endif
+#ifdef OFFT_DEV_REGISTRY  /* developer switch: only the kernels of offt_reg_dev.hip, for quick iteration */
+  reg_dev();
 #else
-  // ---- f64 ----
-  reg_variant<double, 2, 2, 2, 1, 1, 64, false>(0);
-  reg_variant<double, 4, 4, 4, 1, 1, 64, false>(0);
-  reg_variant<double, 8, 8, 8, 1, 1, 64, false>(0);
-  reg_variant<double, 16, 16, 16, 1, 1, 64, false>(0);
-  reg_variant<double, 32, 32, 32, 1, 1, 64, false>(0);
-  reg_variant<double, 64, 8, 8, 8, 1, 8, false>(0);
-  reg_variant<double, 128, 16, 16, 8, 1, 8, false>(0);
-  reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0);
-  reg_variant<double, 512, 32, 32, 16, 1, 8, true>(0, 0);
-  reg_variant<double, 512, 16, 16, 16, 2, 8, true>(1, F_ALL);
-  // static sweep result (profiles/r01_sweep.txt): E=16 (radix 16x16x4, 4 waves/SIMD, no
-  // spills) beats E=32 (radix 32x32, one exchange fewer but 256 VGPRs and 2 waves/SIMD)
-  // on every flavour at 1024^3, so it is the default; E=32 stays selectable as variant 0.
-  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
-  reg_variant<double, 1024, 32, 32, 32, 1, 4, false>(2, 0);
-  reg_variant<double, 2048, 32, 32, 32, 2, 8, true>(0);
-  reg_variant<double, 4096, 32, 32, 32, 4, 4, true>(0);
-  // ---- f32 ----
-  reg_variant<float, 2, 2, 2, 1, 1, 64, false>(0);
-  reg_variant<float, 4, 4, 4, 1, 1, 64, false>(0);
-  reg_variant<float, 8, 8, 8, 1, 1, 64, false>(0);
-  reg_variant<float, 16, 16, 16, 1, 1, 64, false>(0);
-  reg_variant<float, 32, 32, 32, 1, 1, 64, false>(0);
-  reg_variant<float, 64, 8, 8, 8, 1, 16, false>(0);
-  reg_variant<float, 128, 16, 16, 8, 1, 16, false>(0);
-  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
-  // f32 moves twice the elements per HBM byte, so LDS/issue work per byte doubles: the
-  // contiguous/contiguous flavour is fastest with a packed (one 8-B op per element) exchange
-  // on a narrow 8-column panel (2.75 vs 3.63 ms at 1024^3); the flavours with a strided
-  // side keep 16 columns (128-B segments) and the split exchange.  profiles/r01_sweep.txt
-  reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0, F_SS | F_CS | F_SC);
-  reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
-  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
-  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
-  // 2048 f32 (profiles/r01_sweep.txt): wide 16-column panels need E=64 to stay within 512 threads;
-  // the contiguous/contiguous flavour again prefers a narrow packed panel
-  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0, F_SS);
-  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, F_CS | F_SC);
-  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
-  reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
+  reg_pow2_f64();
+  reg_pow2_f32();
+  reg_mixed_f64_a();
+  reg_mixed_f64_b();
+  reg_mixed_f32();
 #endif
 }
 
@@ -746,8 +415,10 @@ bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 bool fast_ok(const offt_pass_desc *d) {
   if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return false;
-  if (!find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0)) return false;
+  const Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0);
+  if (!v) return false;
   if (d->in_split_nfloor > 0 || d->out_split_nfloor > 0) return false;
+  if (v->mixed) return true;  // any split length
   if (d->in_split && !is_pow2(d->in_split)) return false;
   if (d->out_split && !is_pow2(d->out_split)) return false;
   return true;
@@ -788,7 +459,8 @@ int offt_hipk_variant_info(int n, int precision, int variant, int *elems_per_thr
 
 const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
   if (!fast_ok(d)) return "fft_mixed_k";
-  return "fft_panel_k";
+  const Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0);
+  return v->mixed ? "fft_panelx_k" : "fft_panel_k";
 }
 
 int offt_hipk_prepare(int n, int precision) {
@@ -814,6 +486,9 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.in_blk = d->in_block_stride; a.out_blk = d->out_block_stride;
     a.in_shift = d->in_split ? log2i(d->in_split) : 31;
     a.out_shift = d->out_split ? log2i(d->out_split) : 31;
+    a.in_split = d->in_split; a.out_split = d->out_split;
+    a.in_inv = d->in_split ? 1.0f / (float)d->in_split : 0.0f;
+    a.out_inv = d->out_split ? 1.0f / (float)d->out_split : 0.0f;
     a.ncols = d->ncols;
     a.ncp = (d->ncols + v->cols - 1) / v->cols;
     a.nb1 = d->nb1;
@@ -826,7 +501,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
         HIPK_CHECK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
       v->attr_set = true;
     }
-    void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tb.quarter};
+    void *args[] = {(void *)&a, (void *)&in, (void *)&out, v->full_table ? (void *)&tb.full : (void *)&tb.quarter};
     HIPK_CHECK(hipLaunchKernel(v->fn, dim3((unsigned)nblk), dim3(v->threads), args, v->lds, st));
     return 0;
   }
@@ -872,6 +547,12 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   size_t lds = (2 * (size_t)cols + (g.tw_in_lds ? 1 : 0)) * d->n * esz;
   long long nblk = (long long)g.ncp * d->nb1 * d->nb2;
   if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
+  // the panel's LDS footprint allows one or two workgroups per CU: size the workgroup so that the CU still
+  // holds 8-16 waves to cover the LDS round trips between stages
+  static const int mix_nt_env = getenv("OFFT_MIX_THREADS") ? atoi(getenv("OFFT_MIX_THREADS")) : 0;
+  unsigned nt = lds > 80 * 1024 ? 1024 : lds > 40 * 1024 ? 512 : 256;
+  while (nt > 64 && (long long)nt * 2 > (long long)cols * d->n) nt >>= 1;  // at least two elements per thread
+  if (mix_nt_env >= 64 && mix_nt_env <= 1024) nt = (unsigned)mix_nt_env;
   (void)hipGetLastError();  // start from a clean slate: the check below must see only this launch
   if (d->precision == OFFT_PREC_F64) {
     static bool set64 = false;
@@ -879,7 +560,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
       HIPK_CHECK(hipFuncSetAttribute((const void *)fft_mixed_k<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
       set64 = true;
     }
-    hipLaunchKernelGGL(fft_mixed_k<double>, dim3((unsigned)nblk), dim3(256), lds, st, g, (const double2 *)in,
+    hipLaunchKernelGGL(fft_mixed_k<double>, dim3((unsigned)nblk), dim3(nt), lds, st, g, (const double2 *)in,
                        (double2 *)out, (const double2 *)tb.full);
   } else {
     static bool set32 = false;
@@ -887,7 +568,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
       HIPK_CHECK(hipFuncSetAttribute((const void *)fft_mixed_k<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
       set32 = true;
     }
-    hipLaunchKernelGGL(fft_mixed_k<float>, dim3((unsigned)nblk), dim3(256), lds, st, g, (const float2 *)in,
+    hipLaunchKernelGGL(fft_mixed_k<float>, dim3((unsigned)nblk), dim3(nt), lds, st, g, (const float2 *)in,
                        (float2 *)out, (const float2 *)tb.full);
   }
   HIPK_CHECK(hipGetLastError());

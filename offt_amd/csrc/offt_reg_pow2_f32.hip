@@ -1,0 +1,32 @@
+// offt_reg_pow2_f32.hip -- power-of-two single-precision panel kernels
+#include "offt_panel.hpp"
+
+namespace offtk {
+
+void reg_pow2_f32() {
+  // ---- f32 ----
+  reg_variant<float, 2, 2, 2, 1, 1, 64, false>(0);
+  reg_variant<float, 4, 4, 4, 1, 1, 64, false>(0);
+  reg_variant<float, 8, 8, 8, 1, 1, 64, false>(0);
+  reg_variant<float, 16, 16, 16, 1, 1, 64, false>(0);
+  reg_variant<float, 32, 32, 32, 1, 1, 64, false>(0);
+  reg_variant<float, 64, 8, 8, 8, 1, 16, false>(0);
+  reg_variant<float, 128, 16, 16, 8, 1, 16, false>(0);
+  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
+  // f32 moves twice the elements per HBM byte, so LDS/issue work per byte doubles: the
+  // contiguous/contiguous flavour is fastest with a packed (one 8-B op per element) exchange
+  // on a narrow 8-column panel (2.75 vs 3.63 ms at 1024^3); the flavours with a strided
+  // side keep 16 columns (128-B segments) and the split exchange.  profiles/r01_sweep.txt
+  reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
+  // 2048 f32 (profiles/r01_sweep.txt): wide 16-column panels need E=64 to stay within 512 threads;
+  // the contiguous/contiguous flavour again prefers a narrow packed panel
+  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0, F_SS);
+  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
+  reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
+}
+
+}  // namespace offtk

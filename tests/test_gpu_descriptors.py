@@ -96,14 +96,18 @@ def libs(built):
     return L, CB
 
 
-@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 6, 12, 18, 30, 100, 127, 384])
+REPS = int(os.environ.get("OFFT_TEST_DESC_REPS", "6"))
+
+
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 6, 12, 15, 18, 30, 45, 90, 100, 127, 384,
+                               768, 1000])
 def test_random_descriptors(libs, n):
     L, CB = libs
     rng = np.random.default_rng(1000 + n)
     for prec in (api.F64, api.F32):
         assert L.offt_hipk_prepare(n, prec) == 0
         ft, ct = (np.float64, np.complex128) if prec == api.F64 else (np.float32, np.complex64)
-        for _ in range(6 if n <= 512 else 3):
+        for _ in range(REPS if n <= 512 else max(3, REPS // 2)):
             d, nin, nout = make_case(rng, n, prec)
             src = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(ct)
             want = np.full(nout, 7 - 3j, dtype=ct)  # sentinel: untouched elements must stay untouched

@@ -42,6 +42,13 @@ if __name__ == "__main__":
         run(N, 0, 0, reps=3)
         run(N, 1, 0, reps=3)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "vsweep":  # every registered variant, zyx layout
+        prec = api.F32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else api.F64
+        nv = api.lib().offt_hipk_variant_count(N, prec)
+        for v in range(nv):
+            print("variant", v, api.lib().offt_hipk_variant_name(N, prec, v).decode(), flush=True)
+            run(N, 0, 0, (v, v, v), prec=prec, reps=3)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "zyx":
         for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
             run(N, 0, 0, reps=6)
