@@ -334,6 +334,8 @@ void build_registry() {
   reg_pow2_f32();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
+  reg_mixed_f64_c();
+  reg_mixed_f64_d();
   reg_mixed_f32();
 #endif
 }

@@ -728,6 +728,8 @@ void reg_pow2_f64();
 void reg_pow2_f32();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();
+void reg_mixed_f64_c();
+void reg_mixed_f64_d();
 void reg_mixed_f32();
 void reg_dev();
 

@@ -1,10 +1,22 @@
-// offt_reg_mixed_f64_b.hip -- double-precision mixed-radix (2^a 3^b 5^c) panel kernels, group b.
-// Shapes (threads per line, radix order, columns) picked by the static sweep, profiles/r01_mixed_sweep.txt.
+// offt_reg_mixed_f64_b.hip -- double-precision mixed-radix (2^a 3^b 5^c) panel kernels, group b of 4.
+// One shape per length: <T, N, threads per line, R0, R1, R2, columns, split re/im exchange>, the winner of the
+// static sweep over radix order x threads per line x panel width (tools/dev_sweep_mixed.py, every candidate and
+// its time in profiles/r01_mixed_sweep_f64.txt).  The percentage is algorithmic bytes / time of the passes of that
+// length against 8 TB/s, measured on an N^3 grid (an N x 256 x N slab above 1600).
 #include "offt_panel.hpp"
 
 namespace offtk {
 
 void reg_mixed_f64_b() {
+  reg_variantx<double, 120, 8, 15, 8, 1, 16, true>(0);  // 41.8 % of 8 TB/s on the 120-point passes
+  reg_variantx<double, 200, 20, 10, 4, 5, 16, true>(0);  // 56.8 % of 8 TB/s on the 200-point passes
+  reg_variantx<double, 384, 16, 12, 4, 8, 16, true>(0);  // 71.8 % of 8 TB/s on the 384-point passes
+  reg_variantx<double, 600, 40, 15, 8, 5, 8, true>(0);  // 68.1 % of 8 TB/s on the 600-point passes
+  reg_variantx<double, 800, 40, 20, 20, 2, 16, true>(0);  // 58.7 % of 8 TB/s on the 800-point passes
+  reg_variantx<double, 1200, 120, 12, 10, 10, 8, true>(0);  // 58.1 % of 8 TB/s on the 1200-point passes
+  reg_variantx<double, 1536, 96, 16, 16, 6, 8, true>(0);  // 59.8 % of 8 TB/s on the 1536-point passes
+  reg_variantx<double, 2304, 192, 16, 12, 12, 4, true>(0);  // 54.7 % of 8 TB/s on the 2304-point passes
+  reg_variantx<double, 3072, 256, 16, 16, 12, 4, true>(0);  // 50.2 % of 8 TB/s on the 3072-point passes
 }
 
 }  // namespace offtk

@@ -81,6 +81,65 @@ def test_any_length_generic_kernel(built, shape):
         check64(got, want)
 
 
+@pytest.mark.parametrize("shape", [(96, 96, 96), (120, 100, 144), (768, 6, 10), (6, 768, 10), (10, 6, 768), (1000, 4, 12), (4, 12, 1000),
+                                   (12, 1536, 4), (640, 8, 384), (8, 1200, 6), (2, 6, 3072), (3200, 2, 6), (1920, 4, 2)])
+def test_mixed_radix_register_kernel(built, shape):
+    """lengths 2^a 3^b 5^c with a compile-time mixed-radix panel kernel (fft_panelx_k), every layout flavour"""
+    L = api.lib()
+    assert any(L.offt_hipk_has_fast_path(n, api.F64) for n in shape if n & (n - 1)), shape
+    for layout in (dict(S=1), dict(), dict(eq=1)):
+        eq = layout.get("eq", 0)
+        if eq and shape[0] != shape[1]:
+            continue
+        params = {k: v for k, v in layout.items() if k != "eq"}
+        got, _ = gpu_fft(shape, is_equalxy=eq, **params)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, is_equalxy=eq, **params)
+        check64(got, want)
+    # inverse(forward(x)) / N == x, and the r2c z pass on the mixed-radix length
+    f = O.hash_field(*shape)
+    po = api.offt_3d_init(*shape)
+    try:
+        dev, idx = make_input(po, f)
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+        back = dev.cpu().numpy().view(np.complex128)[idx].reshape(shape) / np.prod(shape)
+        assert rel(back, f) <= TOL64
+    finally:
+        api.offt_3d_fin(po)
+    if shape[2] % 2 == 0:
+        got, _ = gpu_fft(shape, is_r2c=1)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, is_r2c=1)
+        check64(got, want)
+
+
+def test_mixed_radix_full_size_768_properties(built):
+    """768^3 (3 * 2^8) on the mixed-radix panel kernel: Parseval, DC term, forward/inverse round trip"""
+    n = 768
+    L = api.lib()
+    po = api.offt_3d_init(n, n, n)
+    try:
+        nel = api.local_elems(po)
+        dev = torch.zeros(nel * 2, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        L.offt_hip_fill_input(po, dev.data_ptr(), 1)
+        torch.cuda.synchronize()
+        x = dev.clone()
+        e_in = float((x * x).sum())
+        dc = torch.view_as_complex(x.view(-1, 2)).sum()
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        torch.cuda.synchronize()
+        X = torch.view_as_complex(dev.view(-1, 2))
+        e_out = float((dev * dev).sum())
+        assert abs(e_out / (e_in * n ** 3) - 1) < 1e-12
+        assert abs(complex(X[0]) - complex(dc)) <= 1e-9 * abs(complex(dc)) + 1e-6
+        api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+        torch.cuda.synchronize()
+        err = float(((dev / n ** 3 - x) ** 2).sum()) ** 0.5 / e_in ** 0.5
+        assert err < TOL64
+    finally:
+        api.offt_3d_fin(po)
+
+
 def test_ramp_closed_form_spot_values(built):
     """run-fft -v prints out[0,0,0..3]; for the ramp these have a closed form"""
     rec = json.load(open(os.path.join(G, "survey_recorded.json")))

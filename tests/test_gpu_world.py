@@ -54,12 +54,16 @@ def test_two_ranks_one_gpu(built, tmp_path):
              dict(N=[128, 64, 32], params=dict(P1=1, T1=16, T2=4)), dict(N=[64, 64, 64], params=dict(P1=1, S=1)),
              dict(N=[64, 64, 64], params=dict(P1=2), eq=1), dict(N=[18, 20, 14], params=dict(P1=1, T1=4, T2=3)),
              dict(N=[64, 32, 128], params=dict(P1=1), r2c=1), dict(N=[256, 256, 256], params=dict(P1=1)),
-             dict(N=[64, 64, 64], params=dict(P1=1), inv=1), dict(N=[64, 32, 16], params=dict(P1=2, T1=8), inv=1)]
+             dict(N=[64, 64, 64], params=dict(P1=1), inv=1), dict(N=[64, 32, 16], params=dict(P1=2, T1=8), inv=1),
+             # mixed-radix panel kernels with per-peer splits that are not powers of two (96 = 2 x 48, 120 = 2 x 60)
+             dict(N=[96, 96, 96], params=dict(P1=1)), dict(N=[120, 96, 100], params=dict(P1=2), inv=1),
+             dict(N=[96, 120, 96], params=dict(P1=1), r2c=1)]
     run_world(2, cases, tmp_path)
 
 
 def test_four_ranks_one_gpu(built, tmp_path):
     cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[64, 64, 64], params=dict(P1=2)),
              dict(N=[64, 64, 64], params=dict(P1=4, S=1)), dict(N=[128, 128, 128], params=dict(P1=1)),
-             dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[128, 128, 128], params=dict())]
+             dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[128, 128, 128], params=dict()),
+             dict(N=[96, 96, 96], params=dict(P1=1)), dict(N=[192, 96, 120], params=dict(P1=2))]
     run_world(4, cases, tmp_path)

@@ -41,7 +41,7 @@ def cfg(N, tpl, r0, r1, r2, cols, split, esz):
 
 def candidates(N, prec, keep=5):
     esz = 8 if prec == "f64" else 4
-    emax_cap = 24 if prec == "f64" else 32
+    emax_cap = int(os.environ.get("EMAX_CAP", "24" if prec == "f64" else "32"))
     out = []
     facts = set()
     for r0 in SMOOTH:
@@ -59,7 +59,7 @@ def candidates(N, prec, keep=5):
             elif r2 in SMOOTH:
                 facts.add((r0, r1, r2))
     for (r0, r1, r2) in facts:
-        for cols in (4, 8, 16):
+        for cols in ([int(os.environ["COLS"])] if os.environ.get("COLS") else (4, 8, 16)):
             for tpl in range(1, 257):
                 if tpl * cols > 1024 or tpl * cols < 64:
                     continue
@@ -73,8 +73,8 @@ def candidates(N, prec, keep=5):
                 if waves < 4:
                     continue
                 # heuristic score: live slots, enough waves per CU, wide panels (>= 128-B segments), few stages
-                score = c["eff"] * min(1.0, waves / 8.0) ** 0.5 * (1.0 if cols * esz * 2 >= 128 else 0.8)
-                score *= (1.0 if c["emax"] >= 12 else 0.85) * (0.97 ** (c["nstage"] - 2) if c["nstage"] > 2 else 1.0)
+                score = c["eff"] * min(1.0, waves / 8.0) ** 0.5 * (1.0 if cols * esz * 2 >= 128 or os.environ.get("COLS") else 0.8)
+                score *= (1.0 if c["emax"] >= 12 or os.environ.get("EMAX_CAP") else 0.85) * (0.97 ** (c["nstage"] - 2) if c["nstage"] > 2 else 1.0)
                 score *= 0.92 if max(r0, r1, r2) > 16 else 1.0      # radix > 16: > 64 live VGPR pairs in one butterfly
                 score *= (64 * cdiv(tpl * cols, 64)) and (tpl * cols) / (64 * cdiv(tpl * cols, 64))  # idle lanes of the last wave
                 out.append((score, tpl, r0, r1, r2, cols, c))
@@ -98,7 +98,7 @@ def candidates(N, prec, keep=5):
 
 def gen(prec, sizes, keep):
     T = "double" if prec == "f64" else "float"
-    d = os.path.join(ROOT, "build", "dev", f"msweep_{prec}")
+    d = os.path.join(ROOT, "build", "dev", f"msweep_{prec}" + os.environ.get("TAG", ""))
     os.makedirs(d, exist_ok=True)
     groups = [[] for _ in range(8)]
     listing = []
@@ -142,7 +142,7 @@ def gen(prec, sizes, keep):
 
 
 def run(prec, sizes):
-    os.environ["OFFT_AMD_LIB"] = os.path.join(ROOT, "build", "dev", f"msweep_{prec}", "liboffthip.so")
+    os.environ["OFFT_AMD_LIB"] = os.path.join(ROOT, "build", "dev", f"msweep_{prec}" + os.environ.get("TAG", ""), "liboffthip.so")
     sys.path.insert(0, ROOT)
     import ctypes as C
     import torch
