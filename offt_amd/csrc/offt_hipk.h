@@ -1,6 +1,6 @@
 /*
  * offt_hipk.h -- thin C ABI between the C host library (offt_host.c) and the
- * hand-written HIP kernels (offt_kernels.hip).  Plain pointers and sizes only.
+ * hand-written HIP kernels (offt_kernels.hip, offt_panel.hpp).  Plain pointers and sizes only.
  *
  * One "pass" = a batch of 1-D FFTs of length n along one axis of a strided
  * complex array, reading a panel [n x COLS] per workgroup, with independent
@@ -53,8 +53,8 @@ typedef struct offt_pass_desc {
 int offt_hipk_prepare(int n, int precision);
 /* Launch one pass on `stream` (a hipStream_t).  No allocation, no sync.        */
 int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void *stream);
-/* 1 if a hand-tuned LDS/register Stockham kernel exists for (n, precision),
- * 0 if the pass will run on the generic any-length kernel.                      */
+/* 1 if a register/LDS Stockham panel kernel exists for (n, precision): powers of two up to 4096
+ * and the swept 2^a 3^b 5^c lengths; 0 if the pass will run on the any-length kernel.        */
 int offt_hipk_has_fast_path(int n, int precision);
 /* number of sweep variants registered for (n, precision, in_contig, out_contig) */
 int offt_hipk_variant_count(int n, int precision);
