@@ -331,12 +331,14 @@ void build_registry() {
   reg_dev();
 #else
   reg_pow2_f64();
+  reg_pow2_f64_1024();
   reg_pow2_f32();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
   reg_mixed_f64_c();
   reg_mixed_f64_d();
-  reg_mixed_f32();
+  reg_mixed_f32_a();
+  reg_mixed_f32_b();
 #endif
 }
 

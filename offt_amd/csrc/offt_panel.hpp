@@ -374,8 +374,8 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 //    stage to stage (the exchange goes through LDS anyway);
 //  * index arithmetic uses division by compile-time constants instead of masks; per-peer
 //    splits of any length (N/p is rarely a power of two here) use a float-reciprocal divide;
-//  * LDS image: one pad element every R0 when R0 is even (stage-0 write stride becomes odd),
-//    none when R0 is odd.
+//  * LDS image: the XOR swizzle when R0 is a multiple of 16, else one pad element every R0 when
+//    R0 is even (stage-0 write stride becomes odd), none when R0 is odd.
 // ---------------------------------------------------------------------------
 constexpr int first_factor(int r) { return r % 2 == 0 ? 2 : (r % 3 == 0 ? 3 : (r % 5 == 0 ? 5 : r)); }
 constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 5 && smooth235(r / first_factor(r))); }
@@ -458,7 +458,11 @@ struct PanelXCfg {
   static constexpr int NSTAGE = (R2 > 1) ? 3 : ((R1 > 1) ? 2 : 1);
   static constexpr int NB0 = cdiv(N / R0, TPL), NB1 = cdiv(N / R1, TPL), NB2 = cdiv(N / R2, TPL);
   static constexpr int EMAX = cmax(NB0 * R0, cmax(R1 > 1 ? NB1 * R1 : 0, R2 > 1 ? NB2 * R2 : 0));
-  static constexpr int PADDIV = (R0 % 2 == 0) ? R0 : 0;
+  // LDS image of one column (see PanelCfg): R0 a multiple of 16 -> the XOR swizzle of fft_panel_k (it only
+  // permutes inside aligned 16-element runs, so any N that is a multiple of 16 works); otherwise one pad
+  // element every R0 when R0 is even (stage-0 write stride becomes odd), nothing when R0 is odd.
+  static constexpr bool SWZ = (R0 % 16 == 0) && (N % 16 == 0);
+  static constexpr int PADDIV = (!SWZ && R0 % 2 == 0) ? R0 : 0;
   static constexpr int NPAD = PADDIV ? N + N / PADDIV : N;
   static constexpr int LSTRIDE = ((NPAD + 31) / 32) * 32 + 4;
   static constexpr bool QUARTER = (N % 4 == 0);
@@ -497,7 +501,11 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
   if constexpr (NSTAGE > 1) {
     for (int i = tid; i < Cfg::QT; i += NT) tw[i] = twt[i];
   }
-  auto pad = [](int i) { if constexpr (PADDIV > 0) return i + i / PADDIV; else return i; };
+  auto pad = [](int i) {
+    if constexpr (Cfg::SWZ) return i ^ ((i / R0) & 15);
+    else if constexpr (PADDIV > 0) return i + i / PADDIV;
+    else return i;
+  };
 
   const unsigned bid = blockIdx.x;
   const int cp = bid % (unsigned)a.ncp;
@@ -516,26 +524,33 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
     const bool valid = (c0 + c) < a.ncols;
     const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
     constexpr int NBF = N / R0;
-    static_for<0, Cfg::NB0 * R0>([&](auto ii) {
-      constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
-      const int q = j + u * TPL;
-      const int n = q + t * NBF;
-      const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
-      V2 val;
-      val.x = 0; val.y = 0;
-      if constexpr (R2C) {
-        if (live) val.x = reinterpret_cast<const T *>(src)[n];
-        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
-      } else {
-        if (live) {
-          long long off;
-          if (a.in_split) { const int blk = fdiv(n, a.in_split, a.in_inv); off = (long long)blk * a.in_blk + (long long)(n - blk * a.in_split) * a.in_axis; }
-          else off = (long long)n * a.in_axis;
-          val = gload(&src[off]);
+    // (the split test is hoisted out of the unrolled loop: the loads of one thread stay back to back)
+    auto load_all = [&](auto has_split) {
+      static_for<0, Cfg::NB0 * R0>([&](auto ii) {
+        constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
+        const int q = j + u * TPL;
+        const int n = q + t * NBF;
+        const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
+        V2 val;
+        val.x = 0; val.y = 0;
+        if constexpr (R2C) {
+          if (live) val.x = reinterpret_cast<const T *>(src)[n];
+          v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+        } else {
+          if (live) {
+            long long off;
+            if constexpr (decltype(has_split)::value) {
+              const int blk = fdiv(n, a.in_split, a.in_inv);
+              off = (long long)blk * a.in_blk + (long long)(n - blk * a.in_split) * a.in_axis;
+            } else off = (long long)n * a.in_axis;
+            val = gload(&src[off]);
+          }
+          v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
         }
-        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
-      }
-    });
+      });
+    };
+    if (a.in_split) load_all(std::true_type{});
+    else load_all(std::false_type{});
   }
 
   // ---------------- stages ---------------------------------------------------
@@ -639,23 +654,29 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
       const bool valid = (c0 + c) < a.ncols;
       V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
       const T sc = (T)a.scale;
-      static_for<0, NB * R>([&](auto ii) {
-        constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-        const int q = j + u * TPL;
-        const int n = q + t * NBF;
-        constexpr int src = u * R + perm_mixed(R, t);
-        const cx<T> x = v[src];
-        V2 w;
-        w.x = x.x * sc;
-        w.y = (a.conj ? -x.y : x.y) * sc;
-        const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
-        if (live && (!R2C || n <= N / 2)) {
-          long long off;
-          if (a.out_split) { const int blk = fdiv(n, a.out_split, a.out_inv); off = (long long)blk * a.out_blk + (long long)(n - blk * a.out_split) * a.out_axis; }
-          else off = (long long)n * a.out_axis;
-          gstore(&dst[off], w);
-        }
-      });
+      auto store_all = [&](auto has_split) {
+        static_for<0, NB * R>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          const int q = j + u * TPL;
+          const int n = q + t * NBF;
+          constexpr int src = u * R + perm_mixed(R, t);
+          const cx<T> x = v[src];
+          V2 w;
+          w.x = x.x * sc;
+          w.y = (a.conj ? -x.y : x.y) * sc;
+          const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
+          if (live && (!R2C || n <= N / 2)) {
+            long long off;
+            if constexpr (decltype(has_split)::value) {
+              const int blk = fdiv(n, a.out_split, a.out_inv);
+              off = (long long)blk * a.out_blk + (long long)(n - blk * a.out_split) * a.out_axis;
+            } else off = (long long)n * a.out_axis;
+            gstore(&dst[off], w);
+          }
+        });
+      };
+      if (a.out_split) store_all(std::true_type{});
+      else store_all(std::false_type{});
     }
   });
 }
@@ -725,12 +746,14 @@ void reg_variantx(int id, int defmask = -1) {
 
 // instantiation groups (offt_reg_*.hip)
 void reg_pow2_f64();
+void reg_pow2_f64_1024();
 void reg_pow2_f32();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();
 void reg_mixed_f64_c();
 void reg_mixed_f64_d();
-void reg_mixed_f32();
+void reg_mixed_f32_a();
+void reg_mixed_f32_b();
 void reg_dev();
 
 }  // namespace offtk

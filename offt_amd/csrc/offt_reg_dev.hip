@@ -8,6 +8,30 @@ void reg_dev() {
   reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
   reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
 #endif
+#ifdef OFFT_DEV_512
+  reg_variant<double, 512, 16, 16, 16, 2, 8, true>(0, F_ALL);
+  reg_variant<double, 512, 16, 16, 8, 4, 8, true>(1, 0);
+  reg_variant<double, 512, 16, 8, 8, 8, 8, true>(2, 0);
+  reg_variant<double, 512, 8, 8, 8, 8, 8, true>(3, 0);
+  reg_variant<double, 512, 16, 16, 8, 4, 16, true>(4, 0);
+  reg_variant<double, 1024, 16, 16, 8, 8, 8, true>(2, 0);
+  reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0, F_ALL);
+  reg_variant<double, 256, 16, 16, 16, 1, 8, true>(1, 0);
+  reg_variant<double, 256, 16, 16, 16, 1, 16, true>(2, 0);
+  reg_variant<double, 256, 8, 8, 8, 4, 8, true>(3, 0);
+#endif
+#ifdef OFFT_DEV_2048
+  reg_variant<double, 2048, 32, 32, 32, 2, 8, true>(0, F_ALL);
+  reg_variant<double, 2048, 16, 16, 16, 8, 8, true>(1, 0);
+  reg_variant<double, 2048, 32, 32, 32, 2, 4, true>(2, 0);
+  reg_variant<double, 2048, 16, 16, 16, 8, 4, true>(3, 0);
+  reg_variantx<double, 2048, 128, 16, 16, 8, 4, true>(4, 0);
+  reg_variantx<double, 2048, 128, 16, 16, 8, 8, true>(5, 0);
+  reg_variant<double, 4096, 32, 32, 32, 4, 4, true>(0, F_ALL);
+  reg_variant<double, 4096, 16, 16, 16, 16, 4, true>(1, 0);
+  reg_variant<double, 4096, 32, 32, 32, 4, 2, true>(2, 0);
+  reg_variantx<double, 4096, 256, 16, 16, 16, 2, true>(3, 0);
+#endif
 #ifdef OFFT_DEV_F32
   reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_CS | F_SC);
   reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);

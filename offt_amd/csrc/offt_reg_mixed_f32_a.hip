@@ -1,23 +1,17 @@
-// offt_reg_mixed_f32.hip -- single-precision mixed-radix (2^a 3^b 5^c) panel kernels (single precision is an
+// offt_reg_mixed_f32_a.hip -- single-precision mixed-radix (2^a 3^b 5^c) panel kernels (single precision is an
 // extension of this library, so only the commonest lengths get a register kernel; the others run on the
 // any-length kernel).  Shapes are the winners of the static sweep, profiles/r01_mixed_sweep_f32.txt.
 #include "offt_panel.hpp"
 
 namespace offtk {
 
-void reg_mixed_f32() {
+void reg_mixed_f32_a() {
   reg_variantx<float, 384, 16, 8, 6, 8, 16, true>(0);  // 64.5 % of 8 TB/s on the 384-point passes
-  reg_variantx<float, 576, 48, 12, 12, 4, 16, true>(0);  // 67.6 % of 8 TB/s on the 576-point passes
   reg_variantx<float, 640, 40, 16, 8, 5, 16, true>(0);  // 47.8 % of 8 TB/s on the 640-point passes
-  reg_variantx<float, 768, 32, 12, 8, 8, 16, true>(0);  // 59.3 % of 8 TB/s on the 768-point passes
   reg_variantx<float, 960, 64, 15, 8, 8, 16, true>(0);  // 53.4 % of 8 TB/s on the 960-point passes
-  reg_variantx<float, 1000, 40, 25, 8, 5, 16, true>(0);  // 43.1 % of 8 TB/s on the 1000-point passes
   reg_variantx<float, 1152, 48, 12, 8, 12, 16, true>(0);  // 49.5 % of 8 TB/s on the 1152-point passes
-  reg_variantx<float, 1200, 40, 15, 8, 10, 16, true>(0);  // 46.5 % of 8 TB/s on the 1200-point passes
   reg_variantx<float, 1280, 44, 16, 8, 10, 16, true>(0);  // 42.9 % of 8 TB/s on the 1280-point passes
-  reg_variantx<float, 1536, 64, 8, 8, 24, 16, true>(0);  // 48.2 % of 8 TB/s on the 1536-point passes
   reg_variantx<float, 1920, 64, 32, 10, 6, 16, true>(0);  // 43.3 % of 8 TB/s on the 1920-point passes
-  reg_variantx<float, 3072, 104, 32, 32, 3, 8, true>(0);  // 41.7 % of 8 TB/s on the 3072-point passes
 }
 
 }  // namespace offtk

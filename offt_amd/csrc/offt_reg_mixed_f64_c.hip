@@ -8,15 +8,15 @@
 namespace offtk {
 
 void reg_mixed_f64_c() {
-  reg_variantx<double, 100, 10, 10, 10, 1, 16, true>(0);  // 32.3 % of 8 TB/s on the 100-point passes
-  reg_variantx<double, 192, 8, 8, 8, 3, 16, true>(0);  // 56.7 % of 8 TB/s on the 192-point passes
-  reg_variantx<double, 320, 16, 10, 8, 4, 8, true>(0);  // 67.1 % of 8 TB/s on the 320-point passes
-  reg_variantx<double, 576, 48, 12, 12, 4, 8, true>(0);  // 70.4 % of 8 TB/s on the 576-point passes
-  reg_variantx<double, 768, 32, 8, 8, 12, 8, true>(0);  // 70.2 % of 8 TB/s on the 768-point passes
-  reg_variantx<double, 1152, 48, 24, 24, 2, 16, true>(0);  // 62.3 % of 8 TB/s on the 1152-point passes
-  reg_variantx<double, 1500, 160, 15, 10, 10, 4, true>(0);  // 46.5 % of 8 TB/s on the 1500-point passes
-  reg_variantx<double, 2000, 100, 20, 20, 5, 4, true>(0);  // 50.4 % of 8 TB/s on the 2000-point passes
-  reg_variantx<double, 3000, 224, 20, 10, 15, 4, true>(0);  // 38.5 % of 8 TB/s on the 3000-point passes
+  reg_variantx<double, 100, 10, 10, 10, 1, 16, true>(0);  // 33.3 % of 8 TB/s on the 100-point passes
+  reg_variantx<double, 192, 8, 8, 8, 3, 16, true>(0);  // 60.9 % of 8 TB/s on the 192-point passes
+  reg_variantx<double, 320, 16, 10, 8, 4, 8, true>(0);  // 66.3 % of 8 TB/s on the 320-point passes
+  reg_variantx<double, 576, 24, 12, 8, 6, 8, true>(0);  // 73.0 % of 8 TB/s on the 576-point passes
+  reg_variantx<double, 768, 32, 12, 8, 8, 8, true>(0);  // 70.3 % of 8 TB/s on the 768-point passes
+  reg_variantx<double, 1152, 48, 24, 24, 2, 16, true>(0);  // 61.8 % of 8 TB/s on the 1152-point passes
+  reg_variantx<double, 1500, 104, 15, 10, 10, 8, true>(0);  // 47.6 % of 8 TB/s on the 1500-point passes
+  reg_variantx<double, 2000, 104, 10, 20, 10, 8, true>(0);  // 54.0 % of 8 TB/s on the 2000-point passes
+  reg_variantx<double, 3000, 208, 20, 15, 10, 4, true>(0);  // 42.5 % of 8 TB/s on the 3000-point passes
 }
 
 }  // namespace offtk

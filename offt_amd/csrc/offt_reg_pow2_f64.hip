@@ -1,4 +1,4 @@
-// offt_reg_pow2_f64.hip -- power-of-two double-precision panel kernels
+// offt_reg_pow2_f64.hip -- power-of-two double-precision panel kernels, lengths up to 512 and above 1024
 #include "offt_panel.hpp"
 
 namespace offtk {
@@ -17,13 +17,11 @@ void reg_pow2_f64() {
   reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0);
   reg_variant<double, 512, 32, 32, 16, 1, 8, true>(0, 0);
   reg_variant<double, 512, 16, 16, 16, 2, 8, true>(1, F_ALL);
-  // static sweep result (profiles/r01_sweep.txt): E=16 (radix 16x16x4, 4 waves/SIMD, no
-  // spills) beats E=32 (radix 32x32, one exchange fewer but 256 VGPRs and 2 waves/SIMD)
-  // on every flavour at 1024^3, so it is the default; E=32 stays selectable as variant 0.
-  reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
-  reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
-  reg_variant<double, 1024, 32, 32, 32, 1, 4, false>(2, 0);
-  reg_variant<double, 2048, 32, 32, 32, 2, 8, true>(0);
+  // 2048 (profiles/r01_sweep.txt): an 8-column panel owns most of a CU's LDS (one workgroup per CU); the
+  // contiguous/contiguous flavour does not need wide panels, and with 4 columns two workgroups fit:
+  // 5.74 vs 7.97 ms on the x pass of a 2048 x 256 x 2048 slab
+  reg_variant<double, 2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<double, 2048, 32, 32, 32, 2, 4, true>(1, F_CC);
   reg_variant<double, 4096, 32, 32, 32, 4, 4, true>(0);
 }
 

@@ -29,7 +29,8 @@ def cfg(N, tpl, r0, r1, r2, cols, split, esz):
     rs = [r for r in (r0, r1, r2) if r > 1]
     nb = [cdiv(N // r, tpl) for r in rs]
     emax = max(b * r for b, r in zip(nb, rs))
-    paddiv = r0 if r0 % 2 == 0 else 0
+    swz = r0 % 16 == 0 and N % 16 == 0
+    paddiv = r0 if (r0 % 2 == 0 and not swz) else 0
     npad = N + N // paddiv if paddiv else N
     lstride = (npad + 31) // 32 * 32 + 4
     ex = cols * lstride * esz * (1 if split else 2) if len(rs) > 1 else 0
@@ -76,6 +77,9 @@ def candidates(N, prec, keep=5):
                 score = c["eff"] * min(1.0, waves / 8.0) ** 0.5 * (1.0 if cols * esz * 2 >= 128 or os.environ.get("COLS") else 0.8)
                 score *= (1.0 if c["emax"] >= 12 or os.environ.get("EMAX_CAP") else 0.85) * (0.97 ** (c["nstage"] - 2) if c["nstage"] > 2 else 1.0)
                 score *= 0.92 if max(r0, r1, r2) > 16 else 1.0      # radix > 16: > 64 live VGPR pairs in one butterfly
+                if os.environ.get("R0"):
+                    if r0 != int(os.environ["R0"]):
+                        continue
                 score *= (64 * cdiv(tpl * cols, 64)) and (tpl * cols) / (64 * cdiv(tpl * cols, 64))  # idle lanes of the last wave
                 out.append((score, tpl, r0, r1, r2, cols, c))
     out.sort(key=lambda t: (-t[0], max(t[2:5]), -t[2]))
@@ -142,7 +146,8 @@ def gen(prec, sizes, keep):
 
 
 def run(prec, sizes):
-    os.environ["OFFT_AMD_LIB"] = os.path.join(ROOT, "build", "dev", f"msweep_{prec}" + os.environ.get("TAG", ""), "liboffthip.so")
+    if os.environ.get("TAG") != "prod" and not os.environ.get("OFFT_AMD_LIB"):  # TAG=prod: the product library's variants
+        os.environ["OFFT_AMD_LIB"] = os.path.join(ROOT, "build", "dev", f"msweep_{prec}" + os.environ.get("TAG", ""), "liboffthip.so")
     sys.path.insert(0, ROOT)
     import ctypes as C
     import torch
@@ -170,14 +175,16 @@ def run(prec, sizes):
                 t = (C.c_double * 3)()
                 L.offt_hip_last_pass_seconds(po, t)
                 tt = t[0] + t[2] if shape[1] != N else t[0] + t[1] + t[2]
-                best = tt if best is None else min(best, tt)
+                if best is None or tt < best:
+                    best, per = tt, (t[0], t[1], t[2])
             api.offt_3d_fin(po)
             del dev
             npass = 2 if shape[1] != N else 3
             E = shape[0] * shape[1] * shape[2]
             frac = npass * 2 * esz * E / best / 8e12
             res.append((frac, v))
-            print(f"N={N} {prec} v{v} {L.offt_hipk_variant_name(N, P, v).decode()}: {best * 1e3:.3f} ms over {npass} passes of {shape} = {frac * 100:.1f}% of 8 TB/s", flush=True)
+            print(f"N={N} {prec} v{v} {L.offt_hipk_variant_name(N, P, v).decode()}: {best * 1e3:.3f} ms over {npass} passes of {shape} = {frac * 100:.1f}% of 8 TB/s"
+                  f"  [z/y/x {per[0] * 1e3:.3f}/{per[1] * 1e3:.3f}/{per[2] * 1e3:.3f} ms]", flush=True)
         if res:
             frac, v = max(res)
             print(f"BEST N={N} {prec} v{v} {frac * 100:.1f}% {L.offt_hipk_variant_name(N, P, v).decode()}", flush=True)
