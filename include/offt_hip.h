@@ -51,7 +51,9 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
 /* run on a caller-owned hipStream_t (NULL = the plan's own stream)             */
 void offt_hip_set_stream(struct _offt_plan *po, void *stream);
 /* 0: offt_3d_execute returns after the GPU finished (timers valid, reference
- *    behaviour); 1: returns after enqueueing (caller synchronises the stream). */
+ *    behaviour); 1: returns after enqueueing (caller synchronises the stream);
+ *    no timing events are recorded then, so back-to-back small transforms pay
+ *    for the kernel launches only.                                              */
 void offt_hip_set_async(struct _offt_plan *po, int async);
 /* select a static-sweep kernel variant per axis (0 = x, 1 = y, 2 = z); -1 default */
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant);

@@ -344,6 +344,7 @@ typedef struct hip_state {
   double out_scale;
   int wpad;
   int async;
+  int timed;            /* this call records timing events (synchronous call, or host-staged) */
   double last_dev_s, pass_s[3];
   int pass_slot[3];
   int warned_in;
@@ -967,11 +968,14 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   }
   d[2].scale = st->out_scale; /* last launch */
   for (int i = 0; i < 3; i++) st->pass_slot[i] = slot[i];
+  /* per-pass timing events only when somebody will read them: in asynchronous mode the call returns before
+   * the GPU has finished, and each record costs a barrier packet (~2 us) between launches -- 20 % of a
+   * 128^3 transform */
   for (int i = 0; i < 3; i++) {
-    be->event_record(st->evp[i], s);
+    if (st->timed) be->event_record(st->evp[i], s);
     if (be->pass(&d[i], src[i], dst[i], s)) return -1;
   }
-  be->event_record(st->evp[3], s);
+  if (st->timed) be->event_record(st->evp[3], s);
   return 0;
 }
 
@@ -1388,12 +1392,13 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     data = st->stage;
     staged = 1;
   }
-  be->event_record(st->ev0, st->s_compute);
+  const int timed = st->timed = !(st->async && !staged);
+  if (timed) be->event_record(st->ev0, st->s_compute);
   int rc;
   if (!st->use_pipeline) rc = execute_single(po, data, direction);
   else if (direction > 0) rc = execute_inverse_multi(po, data);
   else rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, direction);
-  be->event_record(st->ev1, st->s_compute);
+  if (timed) be->event_record(st->ev1, st->s_compute);
   if (rc) { t[ALL] = 99999999.0; return; } /* the reference's failure marker, offt-compute.c:3881 */
   if (st->async && !staged) { t[ALL] = wall_seconds() - t0; return; }
   if (be->stream_sync(st->s_compute)) { t[ALL] = 99999999.0; return; }
