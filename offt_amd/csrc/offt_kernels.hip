@@ -85,6 +85,7 @@ struct GenArgs {
   int conj;
   int real_in;
   int tw_in_lds;
+  unsigned xcd_lim, xcd_gshift;
   int nfac;
   int fac[OFFT_MIX_MAXFAC];
   double scale;
@@ -171,7 +172,7 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
   V2 *twl = buf1 + (size_t)C * N;
   const V2 *tw = a.tw_in_lds ? twl : twf;
   const int tid = threadIdx.x, NT = blockDim.x;
-  const unsigned bid = blockIdx.x;
+  const unsigned bid = panel_of_block(blockIdx.x, a.xcd_lim, a.xcd_gshift);
   const int cp = bid % (unsigned)a.ncp;
   const unsigned rest = bid / (unsigned)a.ncp;
   const int b1 = rest % (unsigned)a.nb1;
@@ -417,6 +418,16 @@ int get_tables(int n, int prec, Tables &out, bool create) {
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// XCD-aware panel order (panel_of_block): runs of G = 32 neighbouring panels per XCD by default,
+// OFFT_XCD_REMAP=0 turns it off, OFFT_XCD_REMAP=<power of two> sets G
+void xcd_order(long long nblk, unsigned *lim, unsigned *gshift) {
+  static const int env = getenv("OFFT_XCD_REMAP") ? atoi(getenv("OFFT_XCD_REMAP")) : 32;
+  unsigned gs = 0;
+  while (env > 1 && (2 << gs) <= env) ++gs;
+  *gshift = gs;
+  *lim = env > 0 ? (unsigned)((nblk >> (gs + 3)) << (gs + 3)) : 0u;
+}
+
 bool fast_ok(const offt_pass_desc *d) {
   if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return false;
   const Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0);
@@ -500,6 +511,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.scale = d->scale;
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
+    xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
     if (!v->attr_set) {
       if (v->lds > 48 * 1024)
         HIPK_CHECK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
@@ -551,6 +563,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   size_t lds = (2 * (size_t)cols + (g.tw_in_lds ? 1 : 0)) * d->n * esz;
   long long nblk = (long long)g.ncp * d->nb1 * d->nb2;
   if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
+  xcd_order(nblk, &g.xcd_lim, &g.xcd_gshift);
   // the panel's LDS footprint allows one or two workgroups per CU: size the workgroup so that the CU still
   // holds 8-16 waves to cover the LDS round trips between stages
   static const int mix_nt_env = getenv("OFFT_MIX_THREADS") ? atoi(getenv("OFFT_MIX_THREADS")) : 0;
