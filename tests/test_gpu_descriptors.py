@@ -52,11 +52,13 @@ def layout(rng, n, ncols, nb1, nb2, split, nfloor, contig):
     return dict(axis=axis, col=col, b1=b1, b2=b2, blk=blk if (split or nfloor) else 0, total=total)
 
 
-def make_case(rng, n, prec):
+def make_case(rng, n, prec, big_grid=False):
     d = Desc()
     d.n, d.precision = n, prec
     d.direction = int(rng.choice([-1, -1, 1]))
     d.ncols, d.nb1, d.nb2 = int(rng.integers(1, 21)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    if big_grid:  # hundreds to thousands of panels: the XCD-aware panel order and its unmapped tail
+        d.ncols, d.nb1, d.nb2 = int(rng.integers(100, 700)), int(rng.integers(3, 12)), int(rng.integers(1, 4))
     d.in_contig, d.out_contig = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     d.variant = -1
     d.scale = float(rng.choice([1.0, 0.5, 1.0 / n]))
@@ -123,3 +125,30 @@ def test_random_descriptors(libs, n):
             scale = np.abs(want).max()
             desc = {f: getattr(d, f) for f, _ in Desc._fields_}
             assert np.abs(got - want).max() <= tol * scale * max(1.0, np.log2(n)), desc
+
+
+@pytest.mark.parametrize("n", [16, 64, 96, 100, 127, 256])
+def test_many_panels_xcd_order(libs, n):
+    """grids of 300 .. 8000 panels with ragged last panels: the XCD-aware panel renumbering (panel_of_block) is a
+    bijection and its tail (blocks that do not fill 8 x 32 panels) keeps launch order"""
+    L, CB = libs
+    rng = np.random.default_rng(7000 + n)
+    for prec in (api.F64, api.F32):
+        assert L.offt_hipk_prepare(n, prec) == 0
+        ft, ct = (np.float64, np.complex128) if prec == api.F64 else (np.float32, np.complex64)
+        for _ in range(3):
+            d, nin, nout = make_case(rng, n, prec, big_grid=True)
+            src = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(ct)
+            want = np.full(nout, 7 - 3j, dtype=ct)
+            assert CB.cpu_backend_run_pass(C.byref(d), src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p)) == 0
+            din = torch.from_numpy(src.view(ft).copy()).cuda()
+            dout = torch.from_numpy(np.full(nout, 7 - 3j, dtype=ct).view(ft).copy()).cuda()
+            torch.cuda.synchronize()
+            rc = L.offt_hipk_fft_pass(C.byref(d), din.data_ptr(), dout.data_ptr(), None)
+            assert rc == 0, L.offt_hipk_last_error()
+            torch.cuda.synchronize()
+            got = dout.cpu().numpy().view(ct)
+            tol = 1e-13 if prec == api.F64 else 5e-6
+            desc = {f: getattr(d, f) for f, _ in Desc._fields_}
+            assert np.abs(got - want).max() <= tol * np.abs(want).max() * max(1.0, np.log2(n)), desc
+
