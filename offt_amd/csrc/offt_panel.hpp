@@ -490,7 +490,11 @@ struct PanelXCfg {
   static constexpr int DATA_VGPR = EMAX * (int)sizeof(T) / 2;
   static constexpr int WPS_REG = DATA_VGPR >= 128 ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
   static constexpr int WPS_MIN = (WAVES + 3) / 4;  // one workgroup must fit on a CU
+#ifdef OFFT_DEV_WPS  /* developer A/B: force the waves-per-SIMD target of the mixed-radix kernels */
+  static constexpr int WPS_E = OFFT_DEV_WPS;
+#else
   static constexpr int WPS_E = WPS < WPS_REG ? (WPS < WPS_MIN ? WPS_MIN : WPS) : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
+#endif
 };
 
 template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
@@ -737,10 +741,13 @@ void reg_variant(int id, int defmask = -1) {
   if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
 }
 
-// mixed-radix (2^a 3^b 5^c) panel kernel: TPL threads per line instead of elements per thread
-template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool SPLIT>
+// mixed-radix (2^a 3^b 5^c) panel kernel: TPL threads per line instead of elements per thread.
+// FLAV limits which (in_contig, out_contig) flavours are instantiated at all (compile time), defmask says for
+// which of them this variant is the default.
+template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool SPLIT, int FLAV = F_ALL>
 void reg_variantx(int id, int defmask = -1) {
   if (defmask < 0) defmask = id == 0 ? F_ALL : 0;
+  defmask &= FLAV;
   using Cfg = PanelXCfg<N, TPL, R0, R1, R2, COLS, SPLIT, T>;
   const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
   char nm[160];
@@ -749,12 +756,16 @@ void reg_variantx(int id, int defmask = -1) {
   auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
     registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::EMAX, Cfg::LDS_BYTES, fn, nm, false, true, !Cfg::QUARTER});
   };
-  add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT>);
-  add(false, false, F_SS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, false, SPLIT>);
-  add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT>);
-  add(false, true, F_SC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, true, SPLIT>);
-  if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
-  if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
+  if constexpr ((FLAV & F_CC) != 0) {
+    add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT>);
+    if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
+  }
+  if constexpr ((FLAV & F_SS) != 0) add(false, false, F_SS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, false, SPLIT>);
+  if constexpr ((FLAV & F_CS) != 0) {
+    add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT>);
+    if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
+  }
+  if constexpr ((FLAV & F_SC) != 0) add(false, true, F_SC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, false, true, SPLIT>);
 }
 
 // instantiation groups (offt_reg_*.hip)
