@@ -338,6 +338,7 @@ void build_registry() {
   reg_mixed_f64_b();
   reg_mixed_f64_c();
   reg_mixed_f64_d();
+  reg_mixed_f64_e();
   reg_mixed_f32_a();
   reg_mixed_f32_b();
 #endif

@@ -378,10 +378,10 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 
 // ---------------------------------------------------------------------------
 // Mixed-radix panel kernel: the same three-stage register/LDS Stockham scheme for
-// lengths N = R0 * R1 * R2 whose radices are products of 2, 3 and 5 (768 = 12 x 8 x 8,
-// 1000 = 10 x 10 x 10, ...).  Differences from fft_panel_k:
-//  * the register butterfly is a mixed-radix decimation in frequency (prime steps 2, 3, 5
-//    with compile-time twiddles w_R^k); its output order is the digit-reversal perm_mixed;
+// lengths N = R0 * R1 * R2 whose radices are products of small primes (2, 3, 5 with hand-written
+// butterflies, 7, 11, 13 as direct DFTs): 768 = 12 x 8 x 8, 1000 = 10 x 10 x 10, 896 = 8 x 8 x 14, ...  Differences from fft_panel_k:
+//  * the register butterfly is a mixed-radix decimation in frequency (prime steps with
+//    compile-time twiddles w_R^k); its output order is the digit-reversal perm_mixed;
 //  * TPL threads share a line and a thread owns ceil((N/R)/TPL) butterflies of a stage, the
 //    last one predicated when TPL does not divide N/R, so the register count may differ from
 //    stage to stage (the exchange goes through LDS anyway);
@@ -390,8 +390,11 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 //  * LDS image: the XOR swizzle when R0 is a multiple of 16, else one pad element every R0 when
 //    R0 is even (stage-0 write stride becomes odd), none when R0 is odd.
 // ---------------------------------------------------------------------------
-constexpr int first_factor(int r) { return r % 2 == 0 ? 2 : (r % 3 == 0 ? 3 : (r % 5 == 0 ? 5 : r)); }
-constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 5 && smooth235(r / first_factor(r))); }
+constexpr int first_factor(int r) {
+  return r % 2 == 0 ? 2 : (r % 3 == 0 ? 3 : (r % 5 == 0 ? 5 : (r % 7 == 0 ? 7 : (r % 11 == 0 ? 11 : (r % 13 == 0 ? 13 : r)))));
+}
+// register radices: products of the primes 2 .. 13
+constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 13 && smooth235(r / first_factor(r))); }
 // X[k] of dft_mixed<R> is left in v[perm_mixed(R, k)]
 constexpr int perm_mixed(int r, int k) {
   if (r <= 1) return 0;
@@ -426,7 +429,7 @@ template <typename T, int R>
 __device__ __forceinline__ void dft_mixed(cx<T> *v) {
   if constexpr (R > 1) {
     constexpr int p = first_factor(R), m = R / p;
-    static_assert(p == 2 || p == 3 || p == 5, "register radix must be 2^a 3^b 5^c");
+    static_assert(p == 2 || p == 3 || p == 5 || p == 7 || p == 11 || p == 13, "register radix must be a product of primes <= 13");
     static_for<0, m>([&](auto bb) {
       constexpr int b = decltype(bb)::value;
       if constexpr (p == 2) {
@@ -442,7 +445,7 @@ __device__ __forceinline__ void dft_mixed(cx<T> *v) {
         v[b] = cx<T>{x0.x + sm.x, x0.y + sm.y};
         v[m + b] = mulwr<T, R, b>(cx<T>{t.x + e.x, t.y + e.y});
         v[2 * m + b] = mulwr<T, R, 2 * b>(cx<T>{t.x - e.x, t.y - e.y});
-      } else {
+      } else if constexpr (p == 5) {
         constexpr T C1 = (T)WRC[5][1], C2 = (T)WRC[5][2], S1 = (T)WRS[5][1], S2 = (T)WRS[5][2];
         const cx<T> x0 = v[b], x1 = v[m + b], x2 = v[2 * m + b], x3 = v[3 * m + b], x4 = v[4 * m + b];
         const cx<T> s1{x1.x + x4.x, x1.y + x4.y}, s2{x2.x + x3.x, x2.y + x3.y};
@@ -456,6 +459,34 @@ __device__ __forceinline__ void dft_mixed(cx<T> *v) {
         v[2 * m + b] = mulwr<T, R, 2 * b>(cx<T>{p2.x + q2.y, p2.y - q2.x});  // p2 - i q2
         v[3 * m + b] = mulwr<T, R, 3 * b>(cx<T>{p2.x - q2.y, p2.y + q2.x});  // p2 + i q2
         v[4 * m + b] = mulwr<T, R, 4 * b>(cx<T>{p1.x - q1.y, p1.y + q1.x});  // p1 + i q1
+      } else {
+        // any odd prime p (7, 11, 13): X_k = x0 + sum_j cos(2 pi j k/p) s_j - i sum_j sin(2 pi j k/p) d_j with
+        // s_j = x_j + x_(p-j), d_j = x_j - x_(p-j), j = 1..(p-1)/2; X_(p-k) is the same with + i.  The path is
+        // HBM-bound, so the h^2 multiply-adds are not worth a Winograd factorisation.
+        constexpr int h = (p - 1) / 2;
+        const cx<T> x0 = v[b];
+        cx<T> sj[h], dj[h];
+        static_for<0, h>([&](auto jj) {
+          constexpr int j = decltype(jj)::value + 1;
+          const cx<T> xa = v[j * m + b], xb = v[(p - j) * m + b];
+          sj[j - 1] = cx<T>{xa.x + xb.x, xa.y + xb.y};
+          dj[j - 1] = cx<T>{xa.x - xb.x, xa.y - xb.y};
+        });
+        cx<T> sum = x0;
+        static_for<0, h>([&](auto jj) { sum.x += sj[decltype(jj)::value].x; sum.y += sj[decltype(jj)::value].y; });
+        v[b] = sum;
+        static_for<0, h>([&](auto kk) {
+          constexpr int k = decltype(kk)::value + 1;
+          cx<T> pc = x0, qs{(T)0, (T)0};
+          static_for<0, h>([&](auto jj) {
+            constexpr int j = decltype(jj)::value + 1;
+            constexpr T c = (T)WRC[p][(j * k) % p], sn = (T)WRS[p][(j * k) % p];
+            pc.x += c * sj[j - 1].x; pc.y += c * sj[j - 1].y;
+            qs.x += sn * dj[j - 1].x; qs.y += sn * dj[j - 1].y;
+          });
+          v[k * m + b] = mulwr<T, R, k * b>(cx<T>{pc.x + qs.y, pc.y - qs.x});              // pc - i qs
+          v[(p - k) * m + b] = mulwr<T, R, (p - k) * b>(cx<T>{pc.x - qs.y, pc.y + qs.x});  // pc + i qs
+        });
       }
     });
     static_for<0, p>([&](auto dd) { dft_mixed<T, m>(v + decltype(dd)::value * m); });
@@ -506,7 +537,7 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
   constexpr int NT = Cfg::NT, NSTAGE = Cfg::NSTAGE, LSTRIDE = Cfg::LSTRIDE, EMAX = Cfg::EMAX;
   constexpr int PADDIV = Cfg::PADDIV;
   static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
-  static_assert(smooth235(R0) && smooth235(R1) && smooth235(R2), "radices must be 2^a 3^b 5^c");
+  static_assert(smooth235(R0) && smooth235(R1) && smooth235(R2), "radices must be products of primes <= 13");
   static_assert(R0 <= 32 && R1 <= 32 && R2 <= 32, "register radix <= 32");
 
   extern __shared__ __align__(16) unsigned char smem[];
@@ -776,6 +807,7 @@ void reg_mixed_f64_a();
 void reg_mixed_f64_b();
 void reg_mixed_f64_c();
 void reg_mixed_f64_d();
+void reg_mixed_f64_e();
 void reg_mixed_f32_a();
 void reg_mixed_f32_b();
 void reg_dev();

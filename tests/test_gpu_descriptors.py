@@ -102,7 +102,7 @@ REPS = int(os.environ.get("OFFT_TEST_DESC_REPS", "6"))
 
 
 @pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 6, 12, 15, 18, 30, 45, 90, 100, 127, 384,
-                               768, 1000])
+                               768, 1000, 448, 896, 1001])
 def test_random_descriptors(libs, n):
     L, CB = libs
     rng = np.random.default_rng(1000 + n)

@@ -82,9 +82,11 @@ def test_any_length_generic_kernel(built, shape):
 
 
 @pytest.mark.parametrize("shape", [(96, 96, 96), (120, 100, 144), (768, 6, 10), (6, 768, 10), (10, 6, 768), (1000, 4, 12), (4, 12, 1000),
-                                   (12, 1536, 4), (640, 8, 384), (8, 1200, 6), (2, 6, 3072), (3200, 2, 6), (1920, 4, 2)])
+                                   (12, 1536, 4), (640, 8, 384), (8, 1200, 6), (2, 6, 3072), (3200, 2, 6), (1920, 4, 2),
+                                   (896, 4, 6), (6, 448, 10), (1001, 2, 4), (4, 6, 1344), (224, 224, 56)])
 def test_mixed_radix_register_kernel(built, shape):
-    """lengths 2^a 3^b 5^c with a compile-time mixed-radix panel kernel (fft_panelx_k), every layout flavour"""
+    """lengths 2^a 3^b 5^c (and 7-smooth ones, 1001 = 7 * 11 * 13) with a compile-time mixed-radix panel kernel
+    (fft_panelx_k), every layout flavour"""
     L = api.lib()
     assert any(L.offt_hipk_has_fast_path(n, api.F64) for n in shape if n & (n - 1)), shape
     for layout in (dict(S=1), dict(), dict(eq=1)):

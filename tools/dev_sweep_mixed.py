@@ -17,7 +17,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMOOTH = [r for r in range(2, 33) if all(p in (2, 3, 5) for p in
+SMOOTH = [r for r in range(2, 33) if all(p in (2, 3, 5, 7, 11, 13) for p in
                                           [q for q in range(2, r + 1) if r % q == 0 and all(q % d for d in range(2, q))])]
 
 
