@@ -333,6 +333,7 @@ void build_registry() {
 #else
   reg_pow2_f64();
   reg_pow2_f64_1024();
+  reg_pow2_f64_anysplit();
   reg_pow2_f32();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
@@ -429,16 +430,21 @@ void xcd_order(long long nblk, unsigned *lim, unsigned *gshift) {
   *lim = env > 0 ? (unsigned)((nblk >> (gs + 3)) << (gs + 3)) : 0u;
 }
 
-bool fast_ok(const offt_pass_desc *d) {
-  if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return false;
-  const Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0);
-  if (!v) return false;
-  if (d->in_split_nfloor > 0 || d->out_split_nfloor > 0) return false;
-  if (v->mixed) return true;  // any split length
-  if (d->in_split && !is_pow2(d->in_split)) return false;
-  if (d->out_split && !is_pow2(d->out_split)) return false;
-  return true;
+// the panel-kernel variant that will run this descriptor, or nullptr (-> any-length kernel)
+Variant *pick_variant(const offt_pass_desc *d) {
+  if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return nullptr;
+  const bool inc = d->in_contig != 0, outc = d->out_contig != 0, r2c = d->real_input != 0;
+  Variant *v = find_variant(d->n, d->precision, inc, outc, r2c ? -1 : d->variant, r2c);
+  if (!v) return nullptr;
+  const bool uneven = d->in_split_nfloor > 0 || d->out_split_nfloor > 0;
+  const bool odd_split = (d->in_split && !is_pow2(d->in_split)) || (d->out_split && !is_pow2(d->out_split));
+  if (v->mixed || !(uneven || odd_split)) return v;
+  // fft_panel_k addresses per-peer blocks with shifts: other block lengths go to the length's fft_panelx_k instance
+  Variant *w = find_variant(d->n, d->precision, inc, outc, VARIANT_ANYSPLIT, r2c);
+  return (w && w->id == VARIANT_ANYSPLIT) ? w : nullptr;
 }
+
+bool fast_ok(const offt_pass_desc *d) { return pick_variant(d) != nullptr; }
 
 int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
@@ -456,7 +462,7 @@ int offt_hipk_variant_count(int n, int precision) {
   std::call_once(g_reg_once, build_registry);
   int c = 0;
   for (auto &v : registry())
-    if (v.n == n && v.prec == precision && v.inc && v.outc && !v.r2c) c = v.id + 1 > c ? v.id + 1 : c;
+    if (v.n == n && v.prec == precision && v.inc && v.outc && !v.r2c && v.id < VARIANT_ANYSPLIT) c = v.id + 1 > c ? v.id + 1 : c;
   return c;
 }
 
@@ -474,8 +480,8 @@ int offt_hipk_variant_info(int n, int precision, int variant, int *elems_per_thr
 }
 
 const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
-  if (!fast_ok(d)) return "fft_mixed_k";
-  const Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, -1, d->real_input != 0);
+  const Variant *v = pick_variant(d);
+  if (!v) return "fft_mixed_k";
   return v->mixed ? "fft_panelx_k" : "fft_panel_k";
 }
 
@@ -494,8 +500,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     return 0;
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
-  if (fast_ok(d)) {
-    Variant *v = find_variant(d->n, d->precision, d->in_contig != 0, d->out_contig != 0, d->real_input ? -1 : d->variant, d->real_input != 0);
+  if (Variant *v = pick_variant(d)) {
     PassArgs a;
     a.in_axis = d->in_axis_stride; a.in_col = d->in_col_stride; a.in_b1 = d->in_b1_stride; a.in_b2 = d->in_b2_stride;
     a.out_axis = d->out_axis_stride; a.out_col = d->out_col_stride; a.out_b1 = d->out_b1_stride; a.out_b2 = d->out_b2_stride;
@@ -505,6 +510,11 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.in_split = d->in_split; a.out_split = d->out_split;
     a.in_inv = d->in_split ? 1.0f / (float)d->in_split : 0.0f;
     a.out_inv = d->out_split ? 1.0f / (float)d->out_split : 0.0f;
+    a.in_nfloor = d->in_split_nfloor; a.out_nfloor = d->out_split_nfloor;
+    a.in_lim = d->in_split_nfloor ? d->in_split * d->in_split_nfloor : d->n;   // even split: every index below lim
+    a.out_lim = d->out_split_nfloor ? d->out_split * d->out_split_nfloor : d->n;
+    a.in_inv1 = 1.0f / (float)(d->in_split + 1);
+    a.out_inv1 = 1.0f / (float)(d->out_split + 1);
     a.ncols = d->ncols;
     a.ncp = (d->ncols + v->cols - 1) / v->cols;
     a.nb1 = d->nb1;

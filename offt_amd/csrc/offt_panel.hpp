@@ -91,6 +91,21 @@ __device__ __forceinline__ unsigned panel_of_block(unsigned bid, unsigned lim, u
   return ((r >> gshift) << (gshift + 3u)) + (x << gshift) + (r & ((1u << gshift) - 1u));
 }
 
+// element offset of axis index n under a per-peer split (SPLIT = false: none): indices below lim = split * nfloor
+// sit in blocks of `split`, the others in blocks of split + 1 -- the reference's uneven A2AV partition
+// (offt-compute.c:132-144); an even split is the case lim >= N.
+template <bool SPLIT>
+__device__ __forceinline__ long long split_offset(int n, int split, float inv, int nfloor, int lim, float inv1, long long blk_stride,
+                                                  long long axis_stride) {
+  if constexpr (!SPLIT) return (long long)n * axis_stride;
+  else {
+    int blk, rem;
+    if (n < lim) { blk = fdiv(n, split, inv); rem = n - blk * split; }
+    else { const int m = n - lim, b = fdiv(m, split + 1, inv1); blk = nfloor + b; rem = m - b * (split + 1); }
+    return (long long)blk * blk_stride + (long long)rem * axis_stride;
+  }
+}
+
 template <int B, int E_, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (B < E_) {
@@ -155,6 +170,9 @@ struct PassArgs {
   int in_shift, out_shift;  // log2(split) or 31 for "no split"            (fft_panel_k)
   int in_split, out_split;  // split length, any value, 0 for "no split"   (fft_panelx_k)
   float in_inv, out_inv;    // 1 / split
+  int in_nfloor, out_nfloor;  // uneven A2AV partition (offt-compute.c:132-144): the first nfloor blocks hold `split`
+  int in_lim, out_lim;        //   indices (axis indices below lim = split * nfloor), the others split + 1;
+  float in_inv1, out_inv1;    //   inv1 = 1 / (split + 1).  Even split: lim >= n.
   int ncols, ncp, nb1;      // ncp = column panels per batch entry
   int conj;                 // 1: inverse transform via conj-in / conj-out
   unsigned xcd_lim;         // XCD-aware panel order for blocks below this index (see panel_of_block), 0 = off
@@ -585,19 +603,13 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
           if (live) val.x = reinterpret_cast<const T *>(src)[n];
           v[decltype(ii)::value] = cx<T>{val.x, (T)0};
         } else {
-          if (live) {
-            long long off;
-            if constexpr (decltype(has_split)::value) {
-              const int blk = fdiv(n, a.in_split, a.in_inv);
-              off = (long long)blk * a.in_blk + (long long)(n - blk * a.in_split) * a.in_axis;
-            } else off = (long long)n * a.in_axis;
-            val = gload(&src[off]);
-          }
+          if (live)
+            val = gload(&src[split_offset<decltype(has_split)::value>(n, a.in_split, a.in_inv, a.in_nfloor, a.in_lim, a.in_inv1, a.in_blk, a.in_axis)]);
           v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
         }
       });
     };
-    if (a.in_split) load_all(std::true_type{});
+    if (a.in_split || a.in_nfloor) load_all(std::true_type{});
     else load_all(std::false_type{});
   }
 
@@ -713,17 +725,11 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
           w.x = x.x * sc;
           w.y = (a.conj ? -x.y : x.y) * sc;
           const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
-          if (live && (!R2C || n <= N / 2)) {
-            long long off;
-            if constexpr (decltype(has_split)::value) {
-              const int blk = fdiv(n, a.out_split, a.out_inv);
-              off = (long long)blk * a.out_blk + (long long)(n - blk * a.out_split) * a.out_axis;
-            } else off = (long long)n * a.out_axis;
-            gstore(&dst[off], w);
-          }
+          if (live && (!R2C || n <= N / 2))
+            gstore(&dst[split_offset<decltype(has_split)::value>(n, a.out_split, a.out_inv, a.out_nfloor, a.out_lim, a.out_inv1, a.out_blk, a.out_axis)], w);
         });
       };
-      if (a.out_split) store_all(std::true_type{});
+      if (a.out_split || a.out_nfloor) store_all(std::true_type{});
       else store_all(std::false_type{});
     }
   });
@@ -743,9 +749,12 @@ struct Variant {
   const void *fn;
   std::string name;
   bool attr_set;
-  bool mixed;       // fft_panelx_k (any split length, quarter or full twiddle table)
+  bool mixed;       // fft_panelx_k (any split length incl. uneven, quarter or full twiddle table)
   bool full_table;
 };
+// id of the fft_panelx_k instance a power-of-two length keeps for per-peer splits fft_panel_k cannot address
+// (uneven, or not a power of two: grids split over 3, 6, ... ranks)
+enum { VARIANT_ANYSPLIT = 100 };
 
 std::vector<Variant> &registry();  // defined in offt_kernels.hip
 
@@ -802,6 +811,7 @@ void reg_variantx(int id, int defmask = -1) {
 // instantiation groups (offt_reg_*.hip)
 void reg_pow2_f64();
 void reg_pow2_f64_1024();
+void reg_pow2_f64_anysplit();
 void reg_pow2_f32();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();

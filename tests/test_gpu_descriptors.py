@@ -152,3 +152,28 @@ def test_many_panels_xcd_order(libs, n):
             desc = {f: getattr(d, f) for f, _ in Desc._fields_}
             assert np.abs(got - want).max() <= tol * np.abs(want).max() * max(1.0, np.log2(n)), desc
 
+
+def test_split_routing(libs):
+    """which kernel a descriptor resolves to: power-of-two blocks -> fft_panel_k; blocks of any other length and
+    the reference's uneven F / F+1 blocks -> the length's fft_panelx_k instance; a length without a register
+    kernel -> the any-length kernel"""
+    L, _ = libs
+    L.offt_hipk_kernel_name.restype = C.c_char_p
+    L.offt_hipk_kernel_name.argtypes = [C.POINTER(Desc)]
+
+    def name(n, in_split=0, in_nfloor=0, out_split=0, out_nfloor=0, prec=api.F64):
+        d = Desc()
+        d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2 = n, prec, -1, 8, 1, 1
+        d.in_contig = d.out_contig = 1
+        d.variant, d.scale = -1, 1.0
+        d.in_split, d.in_split_nfloor, d.out_split, d.out_split_nfloor = in_split, in_nfloor, out_split, out_nfloor
+        return L.offt_hipk_kernel_name(C.byref(d)).decode()
+    assert name(1024) == "fft_panel_k"
+    assert name(1024, out_split=128) == "fft_panel_k"
+    assert name(1024, out_split=341, out_nfloor=2) == "fft_panelx_k"      # 1024 over 3 peers: 341, 341, 342
+    assert name(1024, in_split=170, in_nfloor=2) == "fft_panelx_k"        # 1024 over 6 peers
+    assert name(768, out_split=96) == "fft_panelx_k"
+    assert name(1000, in_split=142, in_nfloor=1) == "fft_panelx_k"        # 1000 over 7 peers
+    assert name(127) == "fft_mixed_k"
+    assert name(1024, out_split=341, out_nfloor=2, prec=api.F32) == "fft_mixed_k"  # no f32 any-split instances
+

@@ -67,3 +67,13 @@ def test_four_ranks_one_gpu(built, tmp_path):
              dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[128, 128, 128], params=dict()),
              dict(N=[96, 96, 96], params=dict(P1=1)), dict(N=[192, 96, 120], params=dict(P1=2))]
     run_world(4, cases, tmp_path)
+
+
+def test_three_ranks_one_gpu_uneven_blocks(built, tmp_path):
+    """3 ranks: nothing divides evenly, every pass addresses the reference's F / F+1 per-peer blocks
+    (offt-compute.c:132-144) -- on the register kernels (fft_panelx_k instances), not the any-length kernel"""
+    cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[128, 64, 256], params=dict(P1=1, T1=8)),
+             dict(N=[100, 96, 120], params=dict(P1=3)), dict(N=[64, 100, 128], params=dict(P1=1), inv=1),
+             dict(N=[128, 96, 64], params=dict(P1=1), r2c=1), dict(N=[20, 14, 18], params=dict(P1=1, S=1))]
+    run_world(3, cases, tmp_path)
+
