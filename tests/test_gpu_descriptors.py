@@ -1,6 +1,6 @@
 """-m gpu: the kernel ABI (offt_hipk_fft_pass) against the test-only CPU interpreter of pass descriptors,
-on randomised descriptors: every (in_contig, out_contig) flavour, per-peer splits on either side (power-of-two
--> register kernels, uneven F/F+1 -> any-length kernel), both batch dimensions, ragged column panels, inverse,
+on randomised descriptors: every (in_contig, out_contig) flavour, per-peer splits on either side (power-of-two,
+any other even length, uneven F/F+1), both batch dimensions, ragged column panels, inverse,
 scale, real input, f32.  This is what the fused pack/unpack of the multi-GPU schedules rests on, and a one-GPU
 box cannot exercise those schedules with real peers."""
 import ctypes as C
