@@ -7,7 +7,7 @@ CC        ?= gcc
 ARCH      ?= gfx950
 CSRC      := offt_amd/csrc
 BUILD     := build
-HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -I$(BUILD)
 CFLAGS    := -std=gnu11 -O2 -g -Wall -Wextra -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude
 
 all: offt_amd/liboffthip.so oracle/liboracle.so
@@ -21,6 +21,11 @@ HIPSRC    := offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f64_1024 offt_reg_pow2
 HIPOBJ    := $(HIPSRC:%=$(BUILD)/%.o)
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/offt_panel.hpp $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h $(CSRC)/offt_wr_consts.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/$*.resource_usage.txt || (cat $(BUILD)/$*.resource_usage.txt; false)
+
+# the device part of offt_panel.hpp as a string inside the library: plan-time specialisation through hipRTC
+$(BUILD)/offt_rtc_source.inc: $(CSRC)/offt_panel.hpp $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h $(CSRC)/offt_wr_consts.h tools/gen_rtc_source.py | $(BUILD)
+	python3 tools/gen_rtc_source.py $@
+$(BUILD)/offt_kernels.o: $(BUILD)/offt_rtc_source.inc
 
 $(BUILD)/offt_host.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backend.h include/offt.h include/offt_hip.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@

@@ -33,8 +33,11 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
 #include "offt_hipk.h"
 #include "offt_panel.hpp"
+#include "offt_rtc_source.inc"
 
 namespace offtk {
 std::vector<Variant> &registry() {
@@ -328,6 +331,7 @@ fill_real_k(T *buf, int kind, int n0, int n1, int n2, int s0, int s1, int s2, lo
 // ---------------------------------------------------------------------------
 std::once_flag g_reg_once;
 void build_registry() {
+  registry().reserve(8192);  // plan-time instances are appended later: no reallocation under a concurrent lookup
 #ifdef OFFT_DEV_REGISTRY  /* developer switch: only the kernels of offt_reg_dev.hip, for quick iteration */
   reg_dev();
 #else
@@ -355,6 +359,195 @@ Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = f
     }
   }
   return def;
+}
+
+// ---------------------------------------------------------------------------
+// Plan-time specialisation.  A length without a precompiled panel kernel whose prime factors are <= 13 gets
+// its own fft_panelx_k instances at offt_hipk_prepare(): the device part of offt_panel.hpp travels inside
+// the library as a string, a shape (radix order, threads per line, panel width) is picked with the scoring of
+// tools/dev_sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours (~4 s each) and the
+// code object is loaded as a module.  OFFT_RTC=0 turns it off; any failure leaves the any-length kernel in
+// charge and says why on stderr once.
+// ---------------------------------------------------------------------------
+struct RtcApi {
+  void *h = nullptr;
+  hiprtcResult (*CreateProgram)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+  hiprtcResult (*AddNameExpression)(hiprtcProgram, const char *) = nullptr;
+  hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char **) = nullptr;
+  hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t *) = nullptr;
+  hiprtcResult (*GetProgramLog)(hiprtcProgram, char *) = nullptr;
+  hiprtcResult (*GetLoweredName)(hiprtcProgram, const char *, const char **) = nullptr;
+  hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t *) = nullptr;
+  hiprtcResult (*GetCode)(hiprtcProgram, char *) = nullptr;
+  hiprtcResult (*DestroyProgram)(hiprtcProgram *) = nullptr;
+};
+RtcApi g_rtc;
+std::mutex g_rtc_mu;
+int g_rtc_state = 0;  // 0 untried, 1 ready, -1 unavailable
+
+bool rtc_load() {
+  if (g_rtc_state) return g_rtc_state > 0;
+  g_rtc_state = -1;
+  // the hipRTC that belongs to the HIP runtime this process already uses (PyTorch bundles both), else the system one
+  std::vector<std::string> cand;
+  Dl_info di;
+  if (dladdr((void *)&hipModuleLoadData, &di) && di.dli_fname) {
+    std::string dir(di.dli_fname);
+    const size_t sl = dir.rfind('/');
+    if (sl != std::string::npos) cand.push_back(dir.substr(0, sl + 1) + "libhiprtc.so");
+  }
+  if (getenv("OFFT_HIPRTC_LIB")) cand.insert(cand.begin(), getenv("OFFT_HIPRTC_LIB"));
+  cand.push_back("libhiprtc.so");
+  cand.push_back("/opt/rocm/lib/libhiprtc.so");
+  for (auto &c : cand) {
+    g_rtc.h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (g_rtc.h) break;
+  }
+  if (!g_rtc.h) return false;
+#define RTC_SYM(name) \
+  g_rtc.name = (decltype(g_rtc.name))dlsym(g_rtc.h, "hiprtc" #name); \
+  if (!g_rtc.name) return false;
+  RTC_SYM(CreateProgram) RTC_SYM(AddNameExpression) RTC_SYM(CompileProgram) RTC_SYM(GetProgramLogSize) RTC_SYM(GetProgramLog)
+  RTC_SYM(GetLoweredName) RTC_SYM(GetCodeSize) RTC_SYM(GetCode) RTC_SYM(DestroyProgram)
+#undef RTC_SYM
+  g_rtc_state = 1;
+  return true;
+}
+
+struct Shape { int tpl, r0, r1, r2, cols; double score; int emax; size_t lds; };
+
+bool smooth13(int n) {
+  for (int p : {2, 3, 5, 7, 11, 13}) while (n % p == 0) n /= p;
+  return n == 1;
+}
+int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+
+// the candidate scoring of tools/dev_sweep_mixed.py (live butterfly slots, waves per CU, panel width, radix size)
+bool choose_shape(int N, int prec, Shape *best) {
+  const int esz = prec == OFFT_PREC_F64 ? 8 : 4, emax_cap = 32, emax_soft = prec == OFFT_PREC_F64 ? 24 : 32;
+  std::vector<int> rad;
+  for (int r = 2; r <= 32; ++r) if (smooth13(r)) rad.push_back(r);
+  best->score = -1;
+  auto consider = [&](int r0, int r1, int r2) {
+    const int rs[3] = {r0, r1, r2};
+    const int nst = r2 > 1 ? 3 : (r1 > 1 ? 2 : 1);
+    for (int cols : {8, 16, 4}) {
+      for (int tpl = 1; tpl <= 256; ++tpl) {
+        const int nt = tpl * cols;
+        if (nt > 1024 || nt < 64) continue;
+        int emax = 0; double eff = 0;
+        for (int s = 0; s < nst; ++s) {
+          const int nb = cdiv_i(N / rs[s], tpl);
+          emax = nb * rs[s] > emax ? nb * rs[s] : emax;
+          eff += (double)N / ((double)tpl * nb * rs[s]);
+        }
+        eff /= nst;
+        if ((nt % 64) && !(eff == 1.0 && nt % 16 == 0)) continue;
+        const bool swz = r0 % 16 == 0 && N % 16 == 0;
+        const int paddiv = (r0 % 2 == 0 && !swz) ? r0 : 0;
+        const int npad = paddiv ? N + N / paddiv : N;
+        const int lstride = (npad + 31) / 32 * 32 + 4;
+        const size_t ex = nst > 1 ? (size_t)cols * lstride * esz : 0;
+        const size_t qt = N % 4 == 0 ? N / 4 + 1 : N;
+        const size_t lds = nst > 1 ? (ex + 15) / 16 * 16 + qt * 2 * esz : 0;
+        if (emax > emax_cap || emax < 6 || lds > 160 * 1024 || eff < 0.74) continue;
+        size_t wg = lds ? (160 * 1024) / lds : 4;
+        wg = wg < 1 ? 1 : (wg > 4 ? 4 : wg);
+        const int waves = (int)wg * cdiv_i(nt, 64);
+        if (waves < 4) continue;
+        double sc = eff * std::sqrt(waves >= 8 ? 1.0 : waves / 8.0) * (cols * esz * 2 >= 128 ? 1.0 : 0.8);
+        sc *= (emax >= 12 ? 1.0 : 0.85) * (nst > 2 ? 0.97 : 1.0) * (emax > emax_soft ? 0.8 : 1.0);  // > 24 f64 points per thread: 2 waves/SIMD
+        const int rmax = r0 > r1 ? (r0 > r2 ? r0 : r2) : (r1 > r2 ? r1 : r2);
+        sc *= rmax > 16 ? 0.92 : 1.0;
+        sc *= (double)nt / (64.0 * cdiv_i(nt, 64));
+        if (sc > best->score + 1e-12) *best = Shape{tpl, r0, r1, r2, cols, sc, emax, lds};
+      }
+    }
+  };
+  for (int r0 : rad) {
+    if (N % r0) continue;
+    const int m = N / r0;
+    if (m == 1) consider(r0, 1, 1);
+    for (int r1 : rad) {
+      if (m % r1) continue;
+      const int r2 = m / r1;
+      if (r2 == 1) consider(r0, r1, 1);
+      else if (r2 <= 32 && smooth13(r2)) consider(r0, r1, r2);
+    }
+  }
+  return best->score > 0;
+}
+
+bool rtc_enabled() {
+  static const bool on = !(getenv("OFFT_RTC") && atoi(getenv("OFFT_RTC")) == 0);
+  return on;
+}
+
+// compile and register fft_panelx_k<T, n, shape> for the four flavours; 0 on success
+int rtc_build(int n, int prec) {
+  std::lock_guard<std::mutex> lk(g_rtc_mu);
+  if (find_variant(n, prec, true, true, -1)) return 0;  // somebody was faster
+  static bool warned = false;
+  auto fail = [&](const char *what, const std::string &detail) {
+    if (!warned) fprintf(stderr, "offt(hip): no plan-time kernel for n=%d (%s%s%s); using the any-length kernel\n", n, what,
+                         detail.empty() ? "" : ": ", detail.c_str());
+    warned = true;
+    return -1;
+  };
+  if (!rtc_load()) return fail("hipRTC library not found", "");
+  Shape sh;
+  if (!choose_shape(n, prec, &sh)) return fail("no panel shape fits", "");
+  const char *T = prec == OFFT_PREC_F64 ? "double" : "float";
+  std::string src;
+  for (const char *p : k_rtc_source_pieces) src += p;
+  hiprtcProgram prog;
+  if (g_rtc.CreateProgram(&prog, src.c_str(), "offt_panel_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail("hiprtcCreateProgram failed", "");
+  const bool flav[4][2] = {{true, true}, {false, false}, {true, false}, {false, true}};
+  std::string expr[4];
+  for (int f = 0; f < 4; ++f) {
+    char b[256];
+    snprintf(b, sizeof b, "offtk::fft_panelx_k<%s, %d, %d, %d, %d, %d, %d, %s, %s, true, false>", T, n, sh.tpl, sh.r0, sh.r1, sh.r2,
+             sh.cols, flav[f][0] ? "true" : "false", flav[f][1] ? "true" : "false");
+    expr[f] = b;
+    g_rtc.AddNameExpression(prog, expr[f].c_str());
+  }
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  if (g_rtc.CompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    g_rtc.GetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) g_rtc.GetProgramLog(prog, &log[0]);
+    g_rtc.DestroyProgram(&prog);
+    return fail("hipRTC compile failed", log.substr(0, 600));
+  }
+  size_t cs = 0;
+  g_rtc.GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  g_rtc.GetCode(prog, code.data());
+  hipModule_t mod;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    g_rtc.DestroyProgram(&prog);
+    return fail("hipModuleLoadData failed", "");
+  }
+  hipFunction_t fn[4];
+  for (int f = 0; f < 4; ++f) {
+    const char *low = nullptr;
+    if (g_rtc.GetLoweredName(prog, expr[f].c_str(), &low) != HIPRTC_SUCCESS || hipModuleGetFunction(&fn[f], mod, low) != hipSuccess) {
+      (void)hipGetLastError();
+      g_rtc.DestroyProgram(&prog);
+      return fail("kernel symbol not found in the compiled module", "");
+    }
+  }
+  g_rtc.DestroyProgram(&prog);
+  char nm[200];
+  snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d split-re/im lds=%zuB [plan-time hipRTC]",
+           prec ? "f32" : "f64", n, sh.r0, sh.r1, sh.r2, sh.tpl, sh.emax, sh.cols, sh.lds);
+  for (int f = 0; f < 4; ++f)
+    registry().push_back(Variant{n, prec, flav[f][0], flav[f][1], 0, true, false, sh.cols, sh.tpl * sh.cols, sh.emax, sh.lds, nullptr, nm,
+                                 false, true, n % 4 != 0, (void *)fn[f]});
+  return 0;
 }
 
 struct Tables {
@@ -488,7 +681,10 @@ const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
 int offt_hipk_prepare(int n, int precision) {
   if (n < 1) { snprintf(g_err, sizeof g_err, "offt_hipk_prepare: bad n=%d", n); return -1; }
   Tables tb;
-  return get_tables(n, precision, tb, true);
+  if (get_tables(n, precision, tb, true)) return -1;
+  // a 13-smooth length of 256 .. 4096 points without a precompiled panel kernel gets one now (best effort)
+  if (rtc_enabled() && n >= 256 && n <= 4096 && smooth13(n) && !find_variant(n, precision, true, true, -1)) (void)rtc_build(n, precision);
+  return 0;
 }
 
 int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void *stream) {
@@ -523,12 +719,16 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
     xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
+    void *args[] = {(void *)&a, (void *)&in, (void *)&out, v->full_table ? (void *)&tb.full : (void *)&tb.quarter};
+    if (v->modfn) {  // plan-time instance: a module function
+      HIPK_CHECK(hipModuleLaunchKernel((hipFunction_t)v->modfn, (unsigned)nblk, 1, 1, v->threads, 1, 1, (unsigned)v->lds, st, args, nullptr));
+      return 0;
+    }
     if (!v->attr_set) {
       if (v->lds > 48 * 1024)
         HIPK_CHECK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
       v->attr_set = true;
     }
-    void *args[] = {(void *)&a, (void *)&in, (void *)&out, v->full_table ? (void *)&tb.full : (void *)&tb.quarter};
     HIPK_CHECK(hipLaunchKernel(v->fn, dim3((unsigned)nblk), dim3(v->threads), args, v->lds, st));
     return 0;
   }

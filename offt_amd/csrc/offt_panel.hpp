@@ -751,6 +751,7 @@ struct Variant {
   bool attr_set;
   bool mixed;       // fft_panelx_k (any split length incl. uneven, quarter or full twiddle table)
   bool full_table;
+  void *modfn;      // hipFunction_t of an instance compiled at plan time (hipRTC), launched instead of fn
 };
 // id of the fft_panelx_k instance a power-of-two length keeps for per-peer splits fft_panel_k cannot address
 // (uneven, or not a power of two: grids split over 3, 6, ... ranks)
@@ -770,7 +771,7 @@ void reg_variant(int id, int defmask = -1) {
   snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d %s lds=%zuB", prec ? "f32" : "f64", N, E, R0,
            R1, R2, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
   auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
-    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false, false, false});
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false, false, false, nullptr});
   };
   add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
   add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
@@ -794,7 +795,7 @@ void reg_variantx(int id, int defmask = -1) {
   snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d %s lds=%zuB", prec ? "f32" : "f64", N,
            R0, R1, R2, TPL, Cfg::EMAX, COLS, SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
   auto add = [&](bool inc, bool outc, int bit, const void *fn, bool r2c = false) {
-    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::EMAX, Cfg::LDS_BYTES, fn, nm, false, true, !Cfg::QUARTER});
+    registry().push_back(Variant{N, prec, inc, outc, id, (defmask & bit) != 0, r2c, COLS, Cfg::NT, Cfg::EMAX, Cfg::LDS_BYTES, fn, nm, false, true, !Cfg::QUARTER, nullptr});
   };
   if constexpr ((FLAV & F_CC) != 0) {
     add(true, true, F_CC, (const void *)fft_panelx_k<T, N, TPL, R0, R1, R2, COLS, true, true, SPLIT>);

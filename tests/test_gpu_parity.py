@@ -114,6 +114,24 @@ def test_mixed_radix_register_kernel(built, shape):
         check64(got, want)
 
 
+@pytest.mark.parametrize("shape", [(432, 6, 10), (10, 6, 1296), (1728, 4, 2), (324, 324, 8), (2500, 2, 4), (6, 2187, 2), (4, 4, 3528)])
+def test_plan_time_specialised_kernel(built, shape):
+    """a 13-smooth length of 256 .. 4096 points without a precompiled panel kernel: offt_3d_init has hipRTC compile
+    fft_panelx_k for it (offt_hipk_prepare); same tolerances, every layout, f32 too"""
+    L = api.lib()
+    big = max(shape)
+    for prec, tol in ((api.F64, None), (api.F32, TOL32)):
+        for layout in (dict(S=1), dict()):
+            got, _ = gpu_fft(shape, precision=prec, **layout)
+            assert L.offt_hipk_has_fast_path(big, prec) == 1, "no plan-time kernel was built (hipRTC missing?)"
+            assert b"plan-time" in L.offt_hipk_variant_name(big, prec, -1)
+            want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)
+            if tol is None:
+                check64(got, want)
+            else:
+                assert rel(got.astype(np.complex128), want) < tol
+
+
 def test_mixed_radix_full_size_768_properties(built):
     """768^3 (3 * 2^8) on the mixed-radix panel kernel: Parseval, DC term, forward/inverse round trip"""
     n = 768

@@ -5,7 +5,7 @@
 set -e
 name=$1; shift
 d=build/dev/$name; mkdir -p $d
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iofft_amd/csrc -Iinclude -DOFFT_DEV_REGISTRY"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iofft_amd/csrc -Iinclude -Ibuild -DOFFT_DEV_REGISTRY"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c offt_amd/csrc/offt_kernels.hip -o $d/k.o &
 /opt/rocm/bin/hipcc $FLAGS "$@" -c offt_amd/csrc/offt_reg_dev.hip -o $d/r.o -Rpass-analysis=kernel-resource-usage 2> $d/res.txt
 wait

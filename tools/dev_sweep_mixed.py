@@ -126,7 +126,7 @@ def gen(prec, sizes, keep):
     srcs.append(src)
     srcs.append(os.path.join(ROOT, "offt_amd", "csrc", "offt_kernels.hip"))
     flags = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "offt_amd", "csrc"),
-             "-I" + os.path.join(ROOT, "include"), "-DOFFT_DEV_REGISTRY", "-Rpass-analysis=kernel-resource-usage"]
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "build"), "-DOFFT_DEV_REGISTRY", "-Rpass-analysis=kernel-resource-usage"]
 
     def cc(s):
         o = os.path.join(d, os.path.basename(s).replace(".hip", ".o"))
