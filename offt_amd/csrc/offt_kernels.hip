@@ -34,6 +34,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <algorithm>
 #include <hip/hiprtc.h>
 #include "offt_hipk.h"
 #include "offt_panel.hpp"
@@ -423,11 +424,11 @@ bool smooth13(int n) {
 int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 
 // the candidate scoring of tools/dev_sweep_mixed.py (live butterfly slots, waves per CU, panel width, radix size)
-bool choose_shape(int N, int prec, Shape *best) {
+bool choose_shapes(int N, int prec, int want, std::vector<Shape> *out) {
   const int esz = prec == OFFT_PREC_F64 ? 8 : 4, emax_cap = 32, emax_soft = prec == OFFT_PREC_F64 ? 24 : 32;
   std::vector<int> rad;
   for (int r = 2; r <= 32; ++r) if (smooth13(r)) rad.push_back(r);
-  best->score = -1;
+  std::vector<Shape> all;
   auto consider = [&](int r0, int r1, int r2) {
     const int rs[3] = {r0, r1, r2};
     const int nst = r2 > 1 ? 3 : (r1 > 1 ? 2 : 1);
@@ -460,7 +461,7 @@ bool choose_shape(int N, int prec, Shape *best) {
         const int rmax = r0 > r1 ? (r0 > r2 ? r0 : r2) : (r1 > r2 ? r1 : r2);
         sc *= rmax > 16 ? 0.92 : 1.0;
         sc *= (double)nt / (64.0 * cdiv_i(nt, 64));
-        if (sc > best->score + 1e-12) *best = Shape{tpl, r0, r1, r2, cols, sc, emax, lds};
+        all.push_back(Shape{tpl, r0, r1, r2, cols, sc, emax, lds});
       }
     }
   };
@@ -475,7 +476,23 @@ bool choose_shape(int N, int prec, Shape *best) {
       else if (r2 <= 32 && smooth13(r2)) consider(r0, r1, r2);
     }
   }
-  return best->score > 0;
+  std::stable_sort(all.begin(), all.end(), [](const Shape &a, const Shape &b) { return a.score > b.score; });
+  // the best shape, then (for a plan-time sweep, OFFT_RTC_SHAPES > 1) the next ones that differ in radix set, thread count
+  // or panel width
+  auto key = [](const Shape &s) { int r[3] = {s.r0, s.r1, s.r2}; std::sort(r, r + 3); return r[0] * 10000 + r[1] * 100 + r[2]; };
+  for (const Shape &c : all) {
+    if ((int)out->size() >= want) break;
+    bool dup = false;
+    int same_set = 0;
+    for (const Shape &o : *out) {
+      if (key(o) == key(c)) {
+        ++same_set;
+        if (o.cols == c.cols && std::abs(o.tpl - c.tpl) < 16 && !(o.r0 != c.r0 && o.tpl == c.tpl)) dup = true;
+      }
+    }
+    if (!dup && same_set < 2) out->push_back(c);
+  }
+  return !out->empty();
 }
 
 bool rtc_enabled() {
@@ -495,8 +512,9 @@ int rtc_build(int n, int prec) {
     return -1;
   };
   if (!rtc_load()) return fail("hipRTC library not found", "");
-  Shape sh;
-  if (!choose_shape(n, prec, &sh)) return fail("no panel shape fits", "");
+  static const int nshapes = getenv("OFFT_RTC_SHAPES") ? atoi(getenv("OFFT_RTC_SHAPES")) : 1;
+  std::vector<Shape> shapes;
+  if (!choose_shapes(n, prec, nshapes < 1 ? 1 : (nshapes > 8 ? 8 : nshapes), &shapes)) return fail("no panel shape fits", "");
   const char *T = prec == OFFT_PREC_F64 ? "double" : "float";
   std::string src;
   for (const char *p : k_rtc_source_pieces) src += p;
@@ -504,14 +522,15 @@ int rtc_build(int n, int prec) {
   if (g_rtc.CreateProgram(&prog, src.c_str(), "offt_panel_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail("hiprtcCreateProgram failed", "");
   const bool flav[4][2] = {{true, true}, {false, false}, {true, false}, {false, true}};
-  std::string expr[4];
-  for (int f = 0; f < 4; ++f) {
-    char b[256];
-    snprintf(b, sizeof b, "offtk::fft_panelx_k<%s, %d, %d, %d, %d, %d, %d, %s, %s, true, false>", T, n, sh.tpl, sh.r0, sh.r1, sh.r2,
-             sh.cols, flav[f][0] ? "true" : "false", flav[f][1] ? "true" : "false");
-    expr[f] = b;
-    g_rtc.AddNameExpression(prog, expr[f].c_str());
-  }
+  std::vector<std::string> expr;
+  for (const Shape &sh : shapes)
+    for (int f = 0; f < 4; ++f) {
+      char b[256];
+      snprintf(b, sizeof b, "offtk::fft_panelx_k<%s, %d, %d, %d, %d, %d, %d, %s, %s, true, false>", T, n, sh.tpl, sh.r0, sh.r1, sh.r2,
+               sh.cols, flav[f][0] ? "true" : "false", flav[f][1] ? "true" : "false");
+      expr.push_back(b);
+      g_rtc.AddNameExpression(prog, expr.back().c_str());
+    }
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
   if (g_rtc.CompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
     size_t ls = 0;
@@ -531,22 +550,26 @@ int rtc_build(int n, int prec) {
     g_rtc.DestroyProgram(&prog);
     return fail("hipModuleLoadData failed", "");
   }
-  hipFunction_t fn[4];
-  for (int f = 0; f < 4; ++f) {
+  std::vector<hipFunction_t> fn(expr.size());
+  for (size_t e = 0; e < expr.size(); ++e) {
     const char *low = nullptr;
-    if (g_rtc.GetLoweredName(prog, expr[f].c_str(), &low) != HIPRTC_SUCCESS || hipModuleGetFunction(&fn[f], mod, low) != hipSuccess) {
+    if (g_rtc.GetLoweredName(prog, expr[e].c_str(), &low) != HIPRTC_SUCCESS || hipModuleGetFunction(&fn[e], mod, low) != hipSuccess) {
       (void)hipGetLastError();
       g_rtc.DestroyProgram(&prog);
       return fail("kernel symbol not found in the compiled module", "");
     }
   }
   g_rtc.DestroyProgram(&prog);
-  char nm[200];
-  snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d split-re/im lds=%zuB [plan-time hipRTC]",
-           prec ? "f32" : "f64", n, sh.r0, sh.r1, sh.r2, sh.tpl, sh.emax, sh.cols, sh.lds);
-  for (int f = 0; f < 4; ++f)
-    registry().push_back(Variant{n, prec, flav[f][0], flav[f][1], 0, true, false, sh.cols, sh.tpl * sh.cols, sh.emax, sh.lds, nullptr, nm,
-                                 false, true, n % 4 != 0, (void *)fn[f]});
+  // variant 0 = the best-scored shape = the default; the others are there for the static sweep (offt_hip_set_variant, -l N)
+  for (size_t k = 0; k < shapes.size(); ++k) {
+    const Shape &sh = shapes[k];
+    char nm[200];
+    snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d split-re/im lds=%zuB [plan-time hipRTC]",
+             prec ? "f32" : "f64", n, sh.r0, sh.r1, sh.r2, sh.tpl, sh.emax, sh.cols, sh.lds);
+    for (int f = 0; f < 4; ++f)
+      registry().push_back(Variant{n, prec, flav[f][0], flav[f][1], (int)k, k == 0, false, sh.cols, sh.tpl * sh.cols, sh.emax, sh.lds, nullptr,
+                                   nm, false, true, n % 4 != 0, (void *)fn[k * 4 + f]});
+  }
   return 0;
 }
 
