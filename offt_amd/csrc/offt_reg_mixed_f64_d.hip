@@ -16,7 +16,8 @@ void reg_mixed_f64_d() {
   reg_variantx<double, 1000, 100, 10, 10, 10, 8, true, F_SS | F_CS | F_SC>(0);  // 57.0 % of 8 TB/s on the 1000-point passes
   reg_variantx<double, 1000, 100, 10, 10, 10, 4, true, F_CC>(1, F_CC);  // contig/contig: two narrow workgroups per CU
   reg_variantx<double, 1440, 96, 16, 6, 15, 8, true>(0);  // 57.8 % of 8 TB/s on the 1440-point passes
-  reg_variantx<double, 1920, 128, 16, 8, 15, 8, true>(0);  // 63.9 % of 8 TB/s on the 1920-point passes
+  reg_variantx<double, 1920, 128, 16, 8, 15, 8, true, F_SS | F_CS | F_SC>(0);  // 63.9 % of 8 TB/s on the 1920-point passes
+  reg_variantx<double, 1920, 128, 16, 8, 15, 4, true, F_CC>(1, F_CC);  // contig/contig: two narrow workgroups per CU
   reg_variantx<double, 2560, 160, 16, 16, 10, 4, true>(0);  // 54.9 % of 8 TB/s on the 2560-point passes
 }
 
