@@ -366,7 +366,7 @@ Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = f
 // Plan-time specialisation.  A length without a precompiled panel kernel whose prime factors are <= 13 gets
 // its own fft_panelx_k instances at offt_hipk_prepare(): the device part of offt_panel.hpp travels inside
 // the library as a string, a shape (radix order, threads per line, panel width) is picked with the scoring of
-// tools/dev_sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours (~4 s each) and the
+// tools/dev_sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours and the two real-input ones (2-4 s in all) and the
 // code object is loaded as a module.  OFFT_RTC=0 turns it off; any failure leaves the any-length kernel in
 // charge and says why on stderr once.
 // ---------------------------------------------------------------------------
@@ -521,14 +521,20 @@ int rtc_build(int n, int prec) {
   hiprtcProgram prog;
   if (g_rtc.CreateProgram(&prog, src.c_str(), "offt_panel_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail("hiprtcCreateProgram failed", "");
-  const bool flav[4][2] = {{true, true}, {false, false}, {true, false}, {false, true}};
+  // four (in_contig, out_contig) flavours per shape, plus the two real-input z-pass flavours of the default shape
+  const bool flav[6][3] = {{true, true, false}, {false, false, false}, {true, false, false}, {false, true, false},
+                           {true, true, true}, {true, false, true}};
+  struct Inst { int shape, f; };
+  std::vector<Inst> inst;
   std::vector<std::string> expr;
-  for (const Shape &sh : shapes)
-    for (int f = 0; f < 4; ++f) {
+  for (size_t k = 0; k < shapes.size(); ++k)
+    for (int f = 0; f < (k == 0 ? 6 : 4); ++f) {
+      const Shape &sh = shapes[k];
       char b[256];
-      snprintf(b, sizeof b, "offtk::fft_panelx_k<%s, %d, %d, %d, %d, %d, %d, %s, %s, true, false>", T, n, sh.tpl, sh.r0, sh.r1, sh.r2,
-               sh.cols, flav[f][0] ? "true" : "false", flav[f][1] ? "true" : "false");
+      snprintf(b, sizeof b, "offtk::fft_panelx_k<%s, %d, %d, %d, %d, %d, %d, %s, %s, true, %s>", T, n, sh.tpl, sh.r0, sh.r1, sh.r2,
+               sh.cols, flav[f][0] ? "true" : "false", flav[f][1] ? "true" : "false", flav[f][2] ? "true" : "false");
       expr.push_back(b);
+      inst.push_back(Inst{(int)k, f});
       g_rtc.AddNameExpression(prog, expr.back().c_str());
     }
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
@@ -561,14 +567,14 @@ int rtc_build(int n, int prec) {
   }
   g_rtc.DestroyProgram(&prog);
   // variant 0 = the best-scored shape = the default; the others are there for the static sweep (offt_hip_set_variant, -l N)
-  for (size_t k = 0; k < shapes.size(); ++k) {
-    const Shape &sh = shapes[k];
+  for (size_t e = 0; e < inst.size(); ++e) {
+    const Shape &sh = shapes[inst[e].shape];
+    const bool *fl = flav[inst[e].f];
     char nm[200];
     snprintf(nm, sizeof nm, "%s N=%d mixed radix=%dx%dx%d threads/line=%d (<=%d elems/thread) cols=%d split-re/im lds=%zuB [plan-time hipRTC]",
              prec ? "f32" : "f64", n, sh.r0, sh.r1, sh.r2, sh.tpl, sh.emax, sh.cols, sh.lds);
-    for (int f = 0; f < 4; ++f)
-      registry().push_back(Variant{n, prec, flav[f][0], flav[f][1], (int)k, k == 0, false, sh.cols, sh.tpl * sh.cols, sh.emax, sh.lds, nullptr,
-                                   nm, false, true, n % 4 != 0, (void *)fn[k * 4 + f]});
+    registry().push_back(Variant{n, prec, fl[0], fl[1], inst[e].shape, inst[e].shape == 0, fl[2], sh.cols, sh.tpl * sh.cols, sh.emax, sh.lds,
+                                 nullptr, nm, false, true, n % 4 != 0, (void *)fn[e]});
   }
   return 0;
 }
