@@ -166,8 +166,16 @@ int main(int argc, char **argv) {
     offt_print_time(t_min_arr);
     if (gflops) {
       double E = (double)Nx * Ny * Nz, fl = 5.0 * E * log2(E), dev = t_min_arr[FFTz] + t_min_arr[FFTy1] + t_min_arr[FFTx] + t_min_arr[PACK1];
-      printf("gflops_wall %.1f gflops_device %.1f hbm_roofline_frac %.4f (6*16*E/p bytes, 8 TB/s)\n", fl / t_min / 1e9,
-             dev > 0 ? fl / dev / 1e9 : 0.0, dev > 0 ? 6.0 * 16.0 * E / p / dev / 8e12 : 0.0);
+      double bytes = 6.0 * 16.0 * E;
+      const char *model = "6*16*E/p bytes";
+      if (is_r2c) { /* real rows in, Nz/2+1 complex out: half the flops of the z pass, y and x passes on the half spectrum */
+        const double Eh = (double)Nx * Ny * (Nz / 2 + 1);
+        fl = 2.5 * E * log2((double)Nz) + 5.0 * Eh * log2((double)Nx * Ny);
+        bytes = 8.0 * E + 16.0 * Eh + 4.0 * 16.0 * Eh;
+        model = "r2c: (8*E + 5*16*Eh)/p bytes, Eh = Nx*Ny*(Nz/2+1)";
+      }
+      printf("gflops_wall %.1f gflops_device %.1f hbm_roofline_frac %.4f (%s, 8 TB/s)\n", fl / t_min / 1e9,
+             dev > 0 ? fl / dev / 1e9 : 0.0, dev > 0 ? bytes / p / dev / 8e12 : 0.0, model);
     }
     if (verbose) {
       printf("p1 %d p2 %d MM3 %d MM4 %d\n", p1, p / p1, MM3p, MM4p);
