@@ -34,6 +34,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <unordered_map>
 #include <algorithm>
 #include <hip/hiprtc.h>
 #include "offt_hipk.h"
@@ -350,14 +351,32 @@ void build_registry() {
 #endif
 }
 
+// (n, precision, flavour) -> registry entries, rebuilt when the registry has grown (plan-time instances): a launch must
+// not scan several hundred variants
+std::mutex g_idx_mu;
+std::unordered_map<unsigned long long, std::vector<int>> g_idx;
+size_t g_idx_size = 0;
+unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c) {
+  return ((unsigned long long)n << 4) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
+}
+
 Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false) {
   std::call_once(g_reg_once, build_registry);
+  std::lock_guard<std::mutex> lk(g_idx_mu);
+  auto &reg = registry();
+  if (g_idx_size != reg.size()) {
+    g_idx.clear();
+    for (size_t i = 0; i < reg.size(); ++i)
+      g_idx[variant_key(reg[i].n, reg[i].prec, reg[i].inc, reg[i].outc, reg[i].r2c)].push_back((int)i);
+    g_idx_size = reg.size();
+  }
+  auto it = g_idx.find(variant_key(n, prec, inc, outc, r2c));
+  if (it == g_idx.end()) return nullptr;
   Variant *def = nullptr;
-  for (auto &v : registry()) {
-    if (v.n == n && v.prec == prec && v.inc == inc && v.outc == outc && v.r2c == r2c) {
-      if (v.id == id) return &v;
-      if (v.is_default) def = &v;
-    }
+  for (int i : it->second) {
+    Variant &v = reg[i];
+    if (v.id == id) return &v;
+    if (v.is_default) def = &v;
   }
   return def;
 }
@@ -567,6 +586,7 @@ int rtc_build(int n, int prec) {
   }
   g_rtc.DestroyProgram(&prog);
   // variant 0 = the best-scored shape = the default; the others are there for the static sweep (offt_hip_set_variant, -l N)
+  std::lock_guard<std::mutex> lk_idx(g_idx_mu);  // lookups index the registry under this lock
   for (size_t e = 0; e < inst.size(); ++e) {
     const Shape &sh = shapes[inst[e].shape];
     const bool *fl = flav[inst[e].f];
