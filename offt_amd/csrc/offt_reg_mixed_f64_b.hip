@@ -9,7 +9,7 @@ namespace offtk {
 
 void reg_mixed_f64_b() {
   reg_variantx<double, 120, 8, 15, 8, 1, 16, true>(0);  // 43.1 % of 8 TB/s on the 120-point passes
-  reg_variantx<double, 200, 20, 10, 5, 4, 16, true>(0);  // 57.0 % of 8 TB/s on the 200-point passes
+  reg_variantx<double, 200, 20, 10, 4, 5, 16, true>(0);  // 57.0 % of 8 TB/s on the 200-point passes
   reg_variantx<double, 384, 16, 12, 4, 8, 16, true>(0);  // 67.9 % of 8 TB/s on the 384-point passes
   reg_variantx<double, 600, 40, 15, 8, 5, 8, true>(0);  // 67.4 % of 8 TB/s on the 600-point passes
   reg_variantx<double, 800, 40, 20, 20, 2, 16, true>(0);  // 59.9 % of 8 TB/s on the 800-point passes

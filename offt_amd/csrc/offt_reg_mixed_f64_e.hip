@@ -12,7 +12,7 @@ void reg_mixed_f64_e() {
   reg_variantx<double, 672, 56, 14, 12, 4, 8, true>(0);  // 73.4 % of 8 TB/s on the 672-point passes
   reg_variantx<double, 896, 64, 14, 8, 8, 8, true, F_SS | F_CS | F_SC>(0);  // 59.7 % of 8 TB/s on the 896-point passes
   reg_variantx<double, 896, 64, 14, 8, 8, 4, true, F_CC>(1, F_CC);  // contig/contig: two narrow workgroups per CU
-  reg_variantx<double, 1001, 96, 13, 7, 11, 8, true, F_SS | F_CS | F_SC>(0);  // 39.8 % of 8 TB/s on the 1001-point passes
+  reg_variantx<double, 1001, 80, 13, 7, 11, 8, true, F_SS | F_CS | F_SC>(0);  // 39.8 % of 8 TB/s on the 1001-point passes
   reg_variantx<double, 1001, 96, 13, 7, 11, 4, true, F_CC>(1, F_CC);  // contig/contig: two narrow workgroups per CU
   reg_variantx<double, 1120, 80, 16, 5, 14, 8, true, F_SS | F_CS | F_SC>(0);  // 57.4 % of 8 TB/s on the 1120-point passes
   reg_variantx<double, 1120, 80, 16, 5, 14, 4, true, F_CC>(1, F_CC);  // contig/contig: two narrow workgroups per CU
