@@ -10,7 +10,7 @@ BUILD     := build
 HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -I$(BUILD)
 CFLAGS    := -std=gnu11 -O2 -g -Wall -Wextra -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude
 
-all: offt_amd/liboffthip.so oracle/liboracle.so
+all: offt_amd/liboffthip.so oracle/liboracle.so tests/liboffthip_test.so
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -34,13 +34,21 @@ $(BUILD)/offt_host.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backe
 # decides which libamdhip64 is in use (PyTorch bundles its own); C programs link
 # -lamdhip64 themselves.
 offt_amd/liboffthip.so: $(HIPOBJ) $(BUILD)/offt_host.o
-	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lm -lpthread
+	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -Wl,-Bsymbolic -ldl -lm -lpthread
+
+# TEST build of the same library: identical kernel objects, the host compiled with -DOFFT_TEST_SEAMS, which adds the two
+# test-only entry points of offt_backend.h (CPU descriptor interpreter for the host-logic tests, host-staged transport
+# for several ranks on one GPU).  The product library above does not contain them.
+$(BUILD)/offt_host_test.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backend.h include/offt.h include/offt_hip.h | $(BUILD)
+	$(CC) $(CFLAGS) -DOFFT_TEST_SEAMS -c $< -o $@
+tests/liboffthip_test.so: $(HIPOBJ) $(BUILD)/offt_host_test.o
+	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -Wl,-Bsymbolic -ldl -lm -lpthread
 
 oracle/liboracle.so: oracle/oracle_fft.c oracle/oracle_offt.c oracle/oracle.h
 	$(CC) -std=gnu11 -O3 -fopenmp -fPIC -shared -Ioracle -o $@ oracle/oracle_fft.c oracle/oracle_offt.c -lm
 
 clean:
-	rm -rf $(BUILD) offt_amd/liboffthip.so oracle/liboracle.so bin
+	rm -rf $(BUILD) offt_amd/liboffthip.so tests/liboffthip_test.so oracle/liboracle.so bin
 
 .PHONY: all clean
 
@@ -63,11 +71,11 @@ endif
 # host logic under AddressSanitizer + UBSan on the CPU test backend (GPU ASan is not available on the pool)
 asan-test: $(HIPOBJ)
 	mkdir -p $(BUILD)/asan
-	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude -c $(CSRC)/offt_host.c -o $(BUILD)/asan/offt_host.o
+	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -DOFFT_TEST_SEAMS -I$(ROCM)/include -I$(CSRC) -Iinclude -c $(CSRC)/offt_host.c -o $(BUILD)/asan/offt_host.o
 	g++ -shared -fsanitize=address,undefined -o $(BUILD)/asan/liboffthip.so $(HIPOBJ) $(BUILD)/asan/offt_host.o -Wl,--allow-shlib-undefined -ldl -lm -lpthread
 	$(CC) -std=gnu11 -O1 -g -fsanitize=address,undefined -fPIC -shared -Ioracle -I$(CSRC) -o $(BUILD)/asan/libcpubackend.so tests/cpu_backend.c oracle/oracle_fft.c -lm
 	cp tests/libcpubackend.so $(BUILD)/asan/libcpubackend.so.orig
 	cp $(BUILD)/asan/libcpubackend.so tests/libcpubackend.so
 	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-	  OFFT_AMD_LIB=$(CURDIR)/$(BUILD)/asan/liboffthip.so python -m pytest tests/test_host_logic.py -x -q; \
+	  OFFT_AMD_TEST_LIB=$(CURDIR)/$(BUILD)/asan/liboffthip.so python -m pytest tests/test_host_logic.py -x -q; \
 	  rc=$$?; cp $(BUILD)/asan/libcpubackend.so.orig tests/libcpubackend.so; exit $$rc

@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
   int Nx = 32, Ny = 32, Nz = 32, p1 = -1, reps = 1, p = 1, rank = 0;
   int fftw_level = 0, ah_strategy = 0, max_loop = 0, tuning_mode = 0, is_W0 = 0, extrapolation_window = 0;
   int is_oned = 0, is_a2a = 0, is_equalxy = 0, is_notest = 0, fft_alg = 0, verbose = 0, is_r2c = 0;
-  int host_data = 0, gflops = 0;
+  int host_data = 0, gflops = 0, rc = 0;
   unsigned fftw_flag = FFTW_ESTIMATE;
 #ifdef OFFT_HARNESS_MPI
   MPI_Init(&argc, &argv);
@@ -114,19 +114,22 @@ int main(int argc, char **argv) {
     if (!rank) printf("only -a 0 (OFFT) is part of this library; FFTW-MPI / P3DFFT / 2DECOMP back-ends are not built\nt_min 999999999.00000\n");
     goto finish;
   }
-  if (p1 == -1 && max_loop == 0) { /* run-fft.c:290-293 */
-    p1 = cp->v[_P1_] = p;
+  if (p1 == -1 && max_loop == 0) {
+    /* run-fft.c:290-293: without -d the reference only SIZES its buffer for p1 = p and leaves custom_params->v[_P1_] at -1, so
+     * the library picks its default mesh (the largest divisor of p that is <= sqrt(p)); the buffer here is sized after init
+     * from the plan itself (offt_hip_local_bytes), for whichever mesh was chosen */
+    p1 = p;
     if (!rank) printf("set p1 = %d\n", p1);
   }
   double t = -now();
   struct _offt_plan *po = offt_3d_init(Nx, Ny, Nz, NULL, NULL, is_r2c, (int)fftw_flag, is_oned, is_a2a, is_equalxy, is_notest,
                                        ah_strategy, max_loop, tuning_mode, is_W0, extrapolation_window, cp);
-  if (!po) { fprintf(stderr, "offt_3d_init failed: %s\n", offt_hip_last_error()); goto finish; }
+  if (!po) { fprintf(stderr, "offt_3d_init failed: %s\n", offt_hip_last_error()); if (!rank) printf("t_min 999999999.00000\n"); rc = 3; goto finish; }
   p1 = po->params->v[_P1_];
   long long bytes = offt_hip_local_bytes(po);
   if (!rank) printf("allocate memory for total # elements %lld\n", bytes / 16);
   double *out = host_data ? (double *)calloc((size_t)bytes, 1) : (double *)offt_hip_malloc(bytes);
-  if (!out) { fprintf(stderr, "allocation of %lld bytes failed\n", bytes); goto finish; }
+  if (!out) { fprintf(stderr, "allocation of %lld bytes failed\n", bytes); if (!rank) printf("t_min 999999999.00000\n"); rc = 4; offt_3d_fin(po); goto finish; }
   if (!rank) { printf("@ FINAL "); print_params(po->params->v); }
   t += now();
   if (!rank) printf("t_init %.5f %.5f %.5f %.5f\n", po->t_init[INIT_ALL], po->t_init[INIT_FFTW], po->t_init[INIT_AH], po->t_init[INIT_BUFFER]);
@@ -141,6 +144,18 @@ int main(int argc, char **argv) {
     double t0 = now();
     offt_3d_execute(po, out, out, 0);
     double tc = now() - t0;
+    if (po->t[ALL] >= 99999999.0) {
+      /* the library's only failure channel (offt-compute.c:3881): a failed launch, an RCCL error, a length no kernel takes.
+       * Say so and fail the run instead of printing timings of an untransformed buffer. */
+      fprintf(stderr, "offt_3d_execute failed on rank %d: %s\n", rank, offt_hip_last_error());
+      printf("t_min 999999999.00000\n");
+      fflush(stdout);
+#ifdef OFFT_HARNESS_MPI
+      MPI_Abort(MPI_COMM_WORLD, 5);
+#endif
+      rc = 5;
+      goto finish_plan;
+    }
     t += tc;
     if (!rank) { printf("t_%d ", r); po->t[ALL] = tc; offt_print_time(po->t); }
     if (tc < t_min) { t_min = tc; memcpy(t_min_arr, po->t, sizeof t_min_arr); }
@@ -182,6 +197,10 @@ int main(int argc, char **argv) {
       for (int z = 0; z < nspot; z++) printf("p %d: %d %d %d: %.5f %.5f\n", rank, 0, 0, z, spot[z][0], spot[z][1]);
     }
   }
+  goto finish_out;
+finish_plan:
+  offt_3d_fin(po);
+finish_out:
   if (host_data) free(out); else offt_hip_free(out);
 finish:
   free(cp);
@@ -189,5 +208,5 @@ finish:
   offt_hip_finalize_world();
   MPI_Finalize();
 #endif
-  return 0;
+  return rc;
 }

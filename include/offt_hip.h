@@ -32,6 +32,12 @@ int offt_hip_set_world(int rank, int size, const void *id128, int device);
 int offt_hip_finalize_world(void);
 int offt_hip_world_rank(void);
 int offt_hip_world_size(void);
+/* number of ranks that answer on the world communicator (an ncclAllReduce of ones); -1 on failure.  Collective.    */
+int offt_hip_world_count(void);
+/* xGMI link probe on the world communicator: grouped ncclSend/ncclRecv of `bytes` per peer, `reps` repetitions after
+ * one warm-up.  mode 0 = all-to-all among all ranks, mode 1 = ring shift by `shift` (one link per direction).
+ * Returns this rank's seconds per repetition, negative on failure.  Collective.                                     */
+double offt_hip_link_probe(int mode, int shift, long long bytes, int reps);
 
 /* ---- plan extensions -------------------------------------------------------- */
 #define OFFT_HIP_F64 0
@@ -55,6 +61,9 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream);
  *    no timing events are recorded then, so back-to-back small transforms pay
  *    for the kernel launches only.                                              */
 void offt_hip_set_async(struct _offt_plan *po, int async);
+/* diagnostics for launchers: leave out the FFT passes (mask 1: exchange-only time) or the exchanges (mask 2:
+ * compute-only time) of the multi-rank schedules.  Results are meaningless while a mask is set; 0 restores.       */
+void offt_hip_set_debug_skip(struct _offt_plan *po, int mask);
 /* select a static-sweep kernel variant per axis (0 = x, 1 = y, 2 = z); -1 default */
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant);
 /* multiply the result by `scale` in the store of the last pass (1.0 = the reference's

@@ -13,6 +13,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFFT_AMD_LIB") or os.path.join(_HERE, "liboffthip.so")  # override: developer A/B builds
 _lib = None
+_by_path = {}
 
 
 def _preload_hip():
@@ -33,14 +34,21 @@ def _preload_hip():
     raise OSError(f"offt_amd: no HIP runtime (libamdhip64) could be loaded: {last}")
 
 
-def load():
+def load(path=None):
+    """Load the product library (default) or another build of it given by `path` (the test build with the
+    test-only seams, a developer A/B build).  Every build is linked -Bsymbolic and loaded RTLD_LOCAL, so two of
+    them can live in one process without binding to each other's symbols."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = path or LIB_PATH
+    if path in _by_path:
+        return _by_path[path]
+    if not os.path.exists(path):
         raise OSError(
-            f"offt_amd: {LIB_PATH} is missing -- run `make` (or __graft_entry__.build()); "
+            f"offt_amd: {path} is missing -- run `make` (or __graft_entry__.build()); "
             "there is no fallback implementation")
     _preload_hip()
-    _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    return _lib
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    _by_path[path] = L
+    if path == LIB_PATH:
+        _lib = L
+    return L

@@ -62,9 +62,23 @@ _bound = None
 def lib():
     """The loaded C-ABI library with argtypes/restypes set."""
     global _bound
-    if _bound is not None:
-        return _bound
-    L = _lib.load()
+    if _bound is None:
+        _bound = bind(_lib.load())
+    return _bound
+
+
+def use_library(path=None):
+    """Route this module through another build of the library (`path`), or back to the product (None).
+    The test-suite uses it for the build that carries the test-only seams (tests/liboffthip_test.so)."""
+    global _bound
+    _bound = bind(_lib.load(path))
+    return _bound
+
+
+def bind(L):
+    """set argtypes/restypes on a loaded build of the library"""
+    if getattr(L, "_offt_bound", False):
+        return L
     PP = C.POINTER(OfftPlan)
     i = C.c_int
     L.offt_3d_init.restype = PP
@@ -109,7 +123,12 @@ def lib():
     L.offt_hipk_variant_name.restype = C.c_char_p
     L.offt_hipk_variant_name.argtypes = [i, i, i]
     L.offt_hipk_has_fast_path.argtypes = [i, i]
-    _bound = L
+    L.offt_hip_world_count.restype = i
+    L.offt_hip_link_probe.restype = C.c_double
+    L.offt_hip_link_probe.argtypes = [i, i, C.c_longlong, i]
+    L.offt_hip_set_debug_skip.restype = None
+    L.offt_hip_set_debug_skip.argtypes = [PP, i]
+    L._offt_bound = True
     return L
 
 

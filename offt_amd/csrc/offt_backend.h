@@ -3,7 +3,8 @@
  * as a table of C function pointers.  The library ships exactly ONE table:
  * HIP kernels + HIP streams/events + RCCL (k_hip_backend in offt_host.c).
  *
- * offt_hip_test_set_backend() exists so that the CPU-only test-suite can run
+ * offt_hip_test_set_backend() (compiled only with -DOFFT_TEST_SEAMS, i.e. into
+ * tests/liboffthip_test.so, never into the product) exists so that the CPU-only test-suite can run
  * the real host logic (decomposition, pass descriptors, tile ring, exchange
  * schedule) in world_size-2 `gloo` processes with a descriptor interpreter
  * that lives under tests/ -- the library itself contains no CPU FFT and never
@@ -45,6 +46,9 @@ void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
 typedef int (*offt_test_transport_fn)(int which, int npeers, const int *peer, const void *const *sendp,
                                       const size_t *sendbytes, void *const *recvp, const size_t *recvbytes);
 void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size);
+/* p1 of the plan whose exchange is in progress on this thread: with it a transport maps (which, group member) to a
+ * world rank -- which 1 = row group (rank_x * p2 + member), 2 = column group (member * p2 + rank_y), 0 = world   */
+int offt_hip_test_current_p1(void);
 
 #ifdef __cplusplus
 }

@@ -69,8 +69,11 @@ typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[OFFT_HIP_UNIQUE_ID_BYTES]; } ncclUniqueId;
 typedef int ncclResult_t;
 #define NCCL_INT8 0
+#define NCCL_INT32 2
 #define NCCL_FLOAT64 8
+#define NCCL_SUM 0
 #define NCCL_MAX 2
+#define NCCL_IN_PROGRESS 7
 static struct {
   void *lib;
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -83,6 +86,9 @@ static struct {
   ncclResult_t (*GroupStart)(void);
   ncclResult_t (*GroupEnd)(void);
   const char *(*GetErrorString)(ncclResult_t);
+  /* optional (older RCCL builds lack them): asynchronous error state of a communicator, abort of its kernels */
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *);
+  ncclResult_t (*CommAbort)(ncclComm_t);
 } R;
 
 static int rccl_load(void) {
@@ -106,6 +112,8 @@ static int rccl_load(void) {
   RSYM(GroupStart, "ncclGroupStart");
   RSYM(GroupEnd, "ncclGroupEnd");
   RSYM(GetErrorString, "ncclGetErrorString");
+  *(void **)(&R.CommGetAsyncError) = dlsym(R.lib, "ncclCommGetAsyncError");
+  *(void **)(&R.CommAbort) = dlsym(R.lib, "ncclCommAbort");
   return 0;
 }
 #define NCHECK(call, fail)                                                                   \
@@ -120,23 +128,41 @@ static int rccl_load(void) {
 /* ------------------------------------------------------------------------- */
 /* world                                                                      */
 /* ------------------------------------------------------------------------- */
-static struct {
+typedef struct world_state {
   int rank, size, device, have_comm;
   ncclComm_t world;
-} G = {0, 1, 0, 0, NULL};
+  int comm_failed; /* an RCCL communicator reported an asynchronous error or a wait timed out: every later execute fails fast */
+} world_state;
+static world_state G_proc = {0, 1, 0, 0, NULL, 0};
 
 static int is_device_ptr(const void *p);
-static void static_sweep(struct _offt_plan *po, void *user_buf);
+static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _offt_params *custom);
 struct hip_state;
 static void slab_teardown(struct hip_state *st);
 static int slab_setup(struct _offt_plan *po, struct hip_state *st);
 
-/* test-only backend override, see offt_backend.h */
-static const offt_backend *g_backend = NULL;
+#ifdef OFFT_TEST_SEAMS
+/* Test-only seams (offt_backend.h), compiled ONLY into tests/liboffthip_test.so (make tests/liboffthip_test.so);
+ * the product library offt_amd/liboffthip.so is built without this block and exports neither function.
+ * The seam state is per thread, so that one test process can run several ranks as threads on one GPU. */
+static _Thread_local world_state G_tls;
+static _Thread_local int G_tls_on = 0;
+#define G (*(G_tls_on ? &G_tls : &G_proc))
+static _Thread_local const offt_backend *g_backend = NULL;
 void offt_hip_test_set_backend(const offt_backend *b, int rank, int size) {
   g_backend = b;
-  if (b) { G.rank = rank; G.size = size; G.have_comm = 0; }
+  G_tls_on = b != NULL;
+  if (b) { memset(&G_tls, 0, sizeof G_tls); G_tls.rank = rank; G_tls.size = size; }
 }
+/* mesh rows of the plan whose exchange is running: a test transport maps (group, member) to a world rank with it */
+static _Thread_local int g_test_cur_p1 = 1;
+int offt_hip_test_current_p1(void) { return g_test_cur_p1; }
+#define TEST_NOTE_MESH(po) (g_test_cur_p1 = (po)->comm->p1)
+#else
+#define G G_proc
+#define g_backend ((const offt_backend *)NULL)
+#define TEST_NOTE_MESH(po) ((void)0)
+#endif
 
 int offt_hip_world_rank(void) { return G.rank; }
 int offt_hip_world_size(void) { return G.size; }
@@ -152,7 +178,11 @@ int offt_hip_get_unique_id(void *id128) {
 int offt_hip_set_world(int rank, int size, const void *id128, int device) {
   if (size < 1 || rank < 0 || rank >= size) { SET_ERR("bad world rank %d size %d", rank, size); return -1; }
   HCHECK(hipSetDevice(device), return -1);
-  G.rank = rank; G.size = size; G.device = device; G.have_comm = 0;
+  if (G.have_comm) { /* a second call replaces the world: do not leak the previous communicator */
+    (void)R.CommDestroy(G.world);
+    G.have_comm = 0; G.world = NULL;
+  }
+  G.rank = rank; G.size = size; G.device = device; G.comm_failed = 0;
   if (size > 1 && !id128) { SET_ERR("offt_hip_set_world: size %d needs an RCCL unique id", size); return -1; }
   if (id128) { /* size 1 with an id: a one-rank communicator, used by the RCCL self-test */
     if (rccl_load()) return -1;
@@ -165,9 +195,34 @@ int offt_hip_set_world(int rank, int size, const void *id128, int device) {
 }
 
 int offt_hip_finalize_world(void) {
-  if (G.have_comm) { R.CommDestroy(G.world); G.have_comm = 0; }
-  G.rank = 0; G.size = 1;
+  if (G.have_comm) {
+    /* after a communication failure the communicator's kernels may still be spinning: abort, do not wait */
+    if (G.comm_failed && R.CommAbort) (void)R.CommAbort(G.world);
+    else (void)R.CommDestroy(G.world);
+    G.have_comm = 0; G.world = NULL;
+  }
+  G.rank = 0; G.size = 1; G.comm_failed = 0;
   return 0;
+}
+
+/* how many ranks answer on the world communicator: an ncclAllReduce(sum) of ones.  A launcher prints it next to
+ * its results so that a run on fewer GPUs than intended cannot pass for the real thing.  -1 on failure. */
+int offt_hip_world_count(void) {
+  if (G.size == 1 && !G.have_comm) return 1;
+  if (!G.have_comm) { SET_ERR("offt_hip_world_count: no communicator"); return -1; }
+  int one = 1, sum = -1, *d = NULL;
+  hipStream_t s = NULL;
+  HCHECK(hipMalloc((void **)&d, sizeof(int)), return -1);
+  HCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), { (void)hipFree(d); return -1; });
+  int rc = -1;
+  if (hipMemcpy(d, &one, sizeof one, hipMemcpyHostToDevice) == hipSuccess &&
+      R.AllReduce(d, d, 1, NCCL_INT32, NCCL_SUM, G.world, s) == 0 && hipStreamSynchronize(s) == hipSuccess &&
+      hipMemcpy(&sum, d, sizeof sum, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = sum;
+  else SET_ERR("offt_hip_world_count: all-reduce failed");
+  (void)hipStreamDestroy(s);
+  (void)hipFree(d);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -334,9 +389,12 @@ typedef struct hip_state {
   void **ev_sa;          /* per z-chunk: every tile's share of the chunk has arrived */
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
+  int Tz2, H2;           /* pencil schedule, phase 2: z-chunk thickness (T2) and number of chunks of exchange 2 / FFTx */
+  void **ev_a2;          /* per z-chunk: the chunk's share of every x-tile has arrived (exchange 2) */
+  int uses_rccl;         /* this plan exchanges over RCCL communicators (watched while waiting) */
+  int skip_mask;         /* diagnostics (offt_hip_set_debug_skip): 1 = no FFT passes, 2 = no exchanges */
   void **send1, **recv1; /* ring */
   void **ev_k1, **ev_a1, **ev_k2;
-  void *ev_a2_last;
   void *send2, *recv2;
   ncclComm_t comm1, comm2; int have_comm1, have_comm2;
   void *stage; size_t stage_bytes;
@@ -388,14 +446,19 @@ static double hb_event_ms(void *a, void *b) {
   }
   return ms;
 }
+#ifdef OFFT_TEST_SEAMS
 /* test-only transport override (offt_backend.h): the HIP kernels, streams and events stay,
  * only the exchange goes through a callback.  Lets several ranks share ONE GPU (RCCL refuses
  * duplicate devices) so the multi-rank schedules run on real device memory in -m gpu tests. */
-static offt_test_transport_fn g_test_transport = NULL;
+static _Thread_local offt_test_transport_fn g_test_transport = NULL;
 void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size) {
   g_test_transport = fn;
-  G.rank = fn ? rank : 0; G.size = fn ? size : 1; G.have_comm = 0;
+  G_tls_on = fn != NULL;
+  if (fn) { memset(&G_tls, 0, sizeof G_tls); G_tls.rank = rank; G_tls.size = size; }
 }
+#else
+#define g_test_transport ((offt_test_transport_fn)NULL)
+#endif
 
 /* all-to-all of one tile inside a row/column group (communicate_a2a(v),
  * offt-compute.c:835-881): grouped ncclSend/ncclRecv over xGMI */
@@ -406,7 +469,8 @@ static int hb_a2a(void *ctx, int which, int npeers, const int *peer_rank_in_comm
     HCHECK(hipStreamSynchronize((hipStream_t)stream), return -1);
     return g_test_transport(which, npeers, peer_rank_in_comm, sendp, sendbytes, recvp, recvbytes);
   }
-  ncclComm_t cm = which == 1 ? st->comm1 : st->comm2;
+  ncclComm_t cm = which == 1 ? st->comm1 : (which == 2 ? st->comm2 : G.world);
+  if (!cm) { SET_ERR("exchange %d without a communicator", which); return -1; }
   NCHECK(R.GroupStart(), return -1);
   for (int a = 0; a < npeers; a++) {
     if (sendbytes[a]) NCHECK(R.Send(sendp[a], sendbytes[a], NCCL_INT8, peer_rank_in_comm[a], cm, (hipStream_t)stream), return -1);
@@ -459,8 +523,11 @@ static void desc_init(offt_pass_desc *d, const hip_state *st, int n, int dir, in
 /* plan                                                                       */
 /* ------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------- */
-/* tile ring: (W1+1) send/receive pairs of T1 x-planes (set_buffer,            */
-/* offt-compute.c:710-746).  Rebuilt when the static sweep tries another T1/W1.*/
+/* pencil schedule buffers (set_buffer, offt-compute.c:710-746):               */
+/*   phase 1: ring of (W1+1) send/receive pairs of T1 x-planes                 */
+/*   phase 2: one send and one receive volume in z-chunks of T2 planes,        */
+/*            per peer [chunk][x][y_l][z in chunk]                             */
+/* Rebuilt when the static sweep tries another T1/W1/T2 or another mesh.       */
 /* ------------------------------------------------------------------------- */
 static void ring_teardown(hip_state *st) {
   const offt_backend *be = st->be;
@@ -476,13 +543,24 @@ static void ring_teardown(hip_state *st) {
   free(st->ev_k1); free(st->ev_a1); free(st->ev_k2);
   st->send1 = st->recv1 = NULL; st->ev_k1 = st->ev_a1 = st->ev_k2 = NULL;
   st->ring = 0;
+  for (int h = 0; h < st->H2 && st->ev_a2; h++) be->event_destroy(st->ev_a2[h]);
+  free(st->ev_a2); st->ev_a2 = NULL;
+  st->H2 = 0;
+  if (st->send2 != st->recv2) be->dfree(st->send2);
+  be->dfree(st->recv2);
+  st->send2 = st->recv2 = NULL;
 }
 
 static int ring_setup(struct _offt_plan *po, hip_state *st) {
   const offt_backend *be = st->be;
   const struct _offt_comm *c = po->comm;
+  const size_t min_msg = (size_t)(getenv("OFFT_MIN_MSG") ? atol(getenv("OFFT_MIN_MSG")) : 4L << 20);
+  /* phase 1: x-tiles of T1 planes, W1 + 1 ring slots.  Unless the caller fixed T1 the tile is merged upwards until a
+   * per-peer message of exchange 1 is at least 4 MiB (the reference's M1/16 was sized for CPU caches and MPI eager limits) */
   st->T = po->params->v[_T1_];
   if (st->T < 1) st->T = 1;
+  if (!st->t1_custom)
+    while (st->T < c->M1 && (size_t)st->T * c->M2 * c->M3 * st->esz < min_msg) st->T *= 2;
   if (st->T > c->M1) st->T = c->M1;
   st->ntiles = (c->M1 + st->T - 1) / st->T;
   int W = po->params->v[_W1_];
@@ -501,6 +579,76 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
     st->ev_k1[r] = be->event_create(); st->ev_a1[r] = be->event_create(); st->ev_k2[r] = be->event_create();
     if (!st->send1[r] || !st->recv1[r]) return -1;
   }
+  /* phase 2: z-chunks of T2 planes (the reference's z-tiles, offt-compute.c:3682-3862).  Unless the caller fixed T2 there
+   * are at most 8 chunks, each a whole number of 8-column panels, and a per-peer message (one x-tile of one chunk) is at
+   * least 4 MiB */
+  int Tz = po->params->v[_T2_];
+  if (Tz < 1) Tz = 1;
+  if (!st->t2_custom) {
+    const int z8 = (c->M3 + 7) / 8;
+    if (Tz < z8) Tz = z8;
+    while (Tz < c->M3 && (size_t)st->T * c->M4 * Tz * st->esz < min_msg) Tz *= 2;
+    if (Tz < c->M3) Tz = (Tz + 7) / 8 * 8;
+  }
+  if (Tz > c->M3) Tz = c->M3;
+  st->Tz2 = Tz;
+  st->H2 = (c->M3 + Tz - 1) / Tz;
+  st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
+  st->recv2 = be->dmalloc(st->blk2 * c->p1 * st->esz);
+  st->send2 = st->x2 ? be->dmalloc(st->blk2 * c->p1 * st->esz) : st->recv2;
+  if (!st->recv2 || !st->send2) return -1;
+  st->ev_a2 = (void **)calloc(st->H2, sizeof(void *));
+  for (int h = 0; h < st->H2; h++) st->ev_a2[h] = be->event_create();
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* everything that depends on the mesh shape p1 x p2: which exchanges exist,   */
+/* the schedule (slab / pencil), its buffers, and the row / column             */
+/* communicators (offt_comm_malloc, offt-compute.c:78-125).  The static sweep  */
+/* rebuilds it per P1 candidate like the tuner does (offt-tuning.c:929).       */
+/* ------------------------------------------------------------------------- */
+static void mesh_teardown(hip_state *st) {
+  ring_teardown(st);
+  slab_teardown(st);
+  if (st->have_comm1) { (void)R.CommDestroy(st->comm1); st->have_comm1 = 0; }
+  if (st->have_comm2) { (void)R.CommDestroy(st->comm2); st->have_comm2 = 0; }
+  st->comm1 = st->comm2 = NULL;
+  st->uses_rccl = 0;
+}
+
+static int mesh_setup(struct _offt_plan *po, hip_state *st) {
+  const struct _offt_comm *c = po->comm;
+  const int p1 = c->p1, p2 = c->p2;
+  const int force = getenv("OFFT_FORCE_A2A") && atoi(getenv("OFFT_FORCE_A2A"));
+  st->x1 = (p2 > 1) || force;
+  st->x2 = (p1 > 1) || force;
+  st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
+                 !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
+  st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
+  if (st->slab_zyx) {
+    st->x2 = 0; /* p1 == 1: there is no second exchange */
+    if (slab_setup(po, st)) return -1;
+  } else if (ring_setup(po, st)) return -1;
+  if (!g_backend && !g_test_transport && (po->p > 1 || force)) {
+    /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
+     * (stride p2) -- offt-compute.c:78-125 */
+    if (!G.have_comm) { SET_ERR("offt_3d_init: world of %d ranks but no RCCL communicator (offt_hip_set_world)", po->p); return -1; }
+    if (G.comm_failed) { SET_ERR("offt_3d_init: the world communicator failed earlier"); return -1; }
+    const int rx = po->rank / p2, ry = po->rank % p2;
+    /* a group that spans the whole world (slab shapes 1 x p, p x 1) simply uses the world
+     * communicator: peer index == world rank.  Real sub-groups are split off; every rank
+     * makes the same sequence of collective ncclCommSplit calls. */
+    if (st->x1) {
+      if (p2 == po->p) st->comm1 = G.world;
+      else { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), return -1); st->have_comm1 = 1; }
+    }
+    if (st->x2) {
+      if (p1 == po->p && !(st->x1 && p2 == po->p)) st->comm2 = G.world; /* never share one comm between two exchanges */
+      else { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), return -1); st->have_comm2 = 1; }
+    }
+    st->uses_rccl = st->x1 || st->x2;
+  }
   return 0;
 }
 
@@ -508,18 +656,13 @@ static void state_free(hip_state *st) {
   if (!st) return;
   const offt_backend *be = st->be;
   be->dfree(st->work);
-  ring_teardown(st);
-  slab_teardown(st);
-  if (st->send2 != st->recv2) be->dfree(st->send2);
-  be->dfree(st->recv2);
+  mesh_teardown(st);
   be->dfree(st->stage);
   be->event_destroy(st->ev0); be->event_destroy(st->ev1);
   for (int i = 0; i < 4; i++) be->event_destroy(st->evp[i]);
-  be->event_destroy(st->ev_a2_last);
   if (st->own_stream) be->stream_destroy(st->s_compute);
-  be->stream_destroy(st->s_comm1); be->stream_destroy(st->s_comm2);
-  if (st->have_comm1) R.CommDestroy(st->comm1);
-  if (st->have_comm2) R.CommDestroy(st->comm2);
+  if (st->s_comm2 != st->s_comm1) be->stream_destroy(st->s_comm2);
+  be->stream_destroy(st->s_comm1);
   free(st);
 }
 
@@ -527,7 +670,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
                                    int is_oned, int is_a2a, int is_equalxy, int is_notest, int ah_strategy,
                                    int max_loop, int tuning_mode, int is_W0, int extrapolation_window,
                                    struct _offt_params *custom_params, int precision) {
-  (void)in; (void)out;
+  (void)in;
   double t0 = wall_seconds();
   if (Nx < 1 || Ny < 1 || Nz < 1) { SET_ERR("offt_3d_init: bad grid %d %d %d", Nx, Ny, Nz); return NULL; }
   if (precision != OFFT_HIP_F64 && precision != OFFT_HIP_F32) { SET_ERR("bad precision %d", precision); return NULL; }
@@ -553,7 +696,6 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     if (po->params->v[_T1_] < 1) po->params->v[_T1_] = 1;
   }
   po->comm = comm_build(po);
-  struct _offt_comm *c = po->comm;
 
   hip_state *st = (hip_state *)calloc(1, sizeof *st);
   po->hip_state = st;
@@ -590,7 +732,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   }
   st->use_pipeline = (po->p > 1) || (getenv("OFFT_FORCE_PIPELINE") && atoi(getenv("OFFT_FORCE_PIPELINE")));
   if (be->prepare(Nx, precision) || be->prepare(Ny, precision) || be->prepare(Nz, precision)) {
-    if (!g_backend) SET_ERR("twiddle setup failed: %s", offt_hipk_last_error());
+    if (!g_backend) SET_ERR("no kernel for this grid: %s", offt_hipk_last_error());
     goto fail;
   }
   st->s_compute = be->stream_create(); st->own_stream = 1;
@@ -605,49 +747,24 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
       if (!st->work) goto fail;
     }
   } else {
-    int p1 = c->p1, p2 = c->p2;
-    const int force = getenv("OFFT_FORCE_A2A") && atoi(getenv("OFFT_FORCE_A2A"));
-    st->x1 = (p2 > 1) || force;
-    st->x2 = (p1 > 1) || force;
-    st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
-                   !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
     st->t1_custom = custom_params && custom_params->v[_T1_] >= 0;
     st->t2_custom = custom_params && custom_params->v[_T2_] >= 0;
-    st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
-    if (st->slab_zyx) {
-      st->x2 = 0; /* p1 == 1: there is no second exchange */
-      if (slab_setup(po, st)) goto fail;
-    } else if (ring_setup(po, st)) goto fail;
-    if (!st->slab_zyx) {
-      st->recv2 = be->dmalloc(st->blk2 * p1 * st->esz);
-      st->send2 = st->x2 ? be->dmalloc(st->blk2 * p1 * st->esz) : st->recv2;
-      if (!st->recv2 || !st->send2) goto fail;
-    }
-    st->ev_a2_last = be->event_create();
-    st->s_comm1 = be->stream_create(); st->s_comm2 = be->stream_create();
-    if (!g_backend && !g_test_transport && (po->p > 1 || force)) {
-      /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
-       * (stride p2) -- offt-compute.c:78-125 */
-      if (!G.have_comm) { SET_ERR("offt_3d_init: world of %d ranks but no RCCL communicator (offt_hip_set_world)", po->p); goto fail; }
-      int rx = po->rank / p2, ry = po->rank % p2;
-      /* a group that spans the whole world (slab shapes 1 x p, p x 1) simply uses the world
-       * communicator: peer index == world rank.  Real sub-groups are split off; every rank
-       * makes the same sequence of collective ncclCommSplit calls. */
-      if (st->x1) {
-        if (p2 == po->p) st->comm1 = G.world;
-        else { NCHECK(R.CommSplit(G.world, rx, ry, &st->comm1, NULL), goto fail); st->have_comm1 = 1; }
-      }
-      if (st->x2) {
-        if (p1 == po->p && !(st->x1 && p2 == po->p)) st->comm2 = G.world; /* never share one comm between the two comm streams */
-        else { NCHECK(R.CommSplit(G.world, ry, rx, &st->comm2, NULL), goto fail); st->have_comm2 = 1; }
-      }
-    }
+    /* Exchange 1 (row group) and exchange 2 (column group) run on different communicators.  Two communicators driven
+     * concurrently from two streams is the one RCCL usage pattern this library cannot rehearse on a single GPU, so by
+     * default both exchanges are issued on ONE comm stream, in the same order on every rank (no cross-communicator wait
+     * cycle is possible); OFFT_COMM_STREAMS=2 gives each exchange its own stream (they then overlap on the wire). */
+    st->s_comm1 = be->stream_create();
+    st->s_comm2 = (getenv("OFFT_COMM_STREAMS") && atoi(getenv("OFFT_COMM_STREAMS")) >= 2) ? be->stream_create() : st->s_comm1;
+    if (!st->s_comm1 || !st->s_comm2) goto fail;
+    if (mesh_setup(po, st)) goto fail;
   }
   po->t_init[INIT_BUFFER] = wall_seconds() - tb0;
-  if (max_loop > 0 && !g_backend) static_sweep(po, out);
+  if (max_loop > 0) static_sweep(po, out, custom_params);
   po->t_init[INIT_ALL] = wall_seconds() - t0;
-  if (!po->rank) /* offt-compute.c:3469-3471 */
+  if (!po->rank) { /* offt-compute.c:3469-3471 */
+    const struct _offt_comm *c = po->comm;
     printf("M1 %d M2 %d M3 %d M4 %d m1 %d m2 %d m3 %d m4 %d\n", c->M1, c->M2, c->M3, c->M4, c->m1, c->m2, c->m3, c->m4);
+  }
   return po;
 fail:
   state_free(st);
@@ -697,30 +814,85 @@ static void db_append(const char *path, const int *v, double perf) {
   fclose(f);
 }
 
-static double sweep_time_point(struct _offt_plan *po, void *buf) {
+/* max over all ranks of one double -- collective: EVERY rank of the world calls it, also after a local failure (it
+ * then contributes a large value), so that no rank is left alone inside an exchange.  It is an all-to-all of 8 bytes on
+ * the world group through the backend's own exchange (which = 0: peer index == world rank), so it works over RCCL,
+ * over the shared-GPU test transport and on the CPU test backend alike.  0 on success. */
+static int world_max(struct _offt_plan *po, double *v) {
   hip_state *st = (hip_state *)po->hip_state;
+  const offt_backend *be = st->be;
+  const int p = po->p;
+  if (p == 1) return 0;
+  TEST_NOTE_MESH(po);
+  double *d = (double *)be->dmalloc(sizeof(double) * 2 * (size_t)p), *h = (double *)malloc(sizeof(double) * 2 * (size_t)p);
+  if (!d || !h) { be->dfree(d); free(h); return -1; }
+  for (int a = 0; a < p; a++) { h[a] = *v; h[p + a] = 0; }
+  const void *sp[p]; void *rp[p]; size_t sb[p], rb[p]; int pr[p];
+  for (int a = 0; a < p; a++) { pr[a] = a; sp[a] = d + a; rp[a] = d + p + a; sb[a] = rb[a] = sizeof(double); }
+  int rc = 0;
+  if (g_backend) memcpy(d, h, sizeof(double) * 2 * p);
+  else if (hipMemcpy(d, h, sizeof(double) * 2 * p, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+  if (!rc) rc = be->a2a(st, 0, p, pr, sp, sb, rp, rb, st->s_compute);
+  if (!rc) rc = be->stream_sync(st->s_compute);
+  if (!rc) {
+    if (g_backend) memcpy(h, d, sizeof(double) * 2 * p);
+    else if (hipMemcpy(h, d, sizeof(double) * 2 * p, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+  }
+  if (!rc) for (int a = 0; a < p; a++) if (h[p + a] > *v) *v = h[p + a];
+  be->dfree(d); free(h);
+  if (rc) *v = 99999999.0;
+  return rc;
+}
+
+/* time one point like the tuner does (offt-tuning.c:955-975: one warm-up, TUNING_REPS executes), max over ranks.
+ * `setup_rc` is this rank's result of building the point: all ranks first agree whether everybody could build it. */
+static double sweep_time_point(struct _offt_plan *po, void *buf, int setup_rc) {
+  hip_state *st = (hip_state *)po->hip_state;
+  double bad = setup_rc ? 1.0 : 0.0;
+  if (world_max(po, &bad) || bad > 0.0) return 99999999.0; /* somebody could not build this point: nobody runs it */
   double best = 1e30;
   offt_3d_execute_dir(po, buf, buf, -1); /* warm-up */
-  if (po->t[ALL] >= 99999999.0) return 99999999.0;
-  for (int r = 0; r < TUNING_REPS; r++) {
+  int failed = po->t[ALL] >= 99999999.0;
+  for (int r = 0; r < TUNING_REPS && !failed; r++) {
     offt_3d_execute_dir(po, buf, buf, -1);
-    if (po->t[ALL] >= 99999999.0) return 99999999.0;
-    if (st->last_dev_s < best) best = st->last_dev_s;
+    if (po->t[ALL] >= 99999999.0) failed = 1;
+    /* device time; the CPU test backend has no device clock, there the wall time of the call ranks the points */
+    const double tpt = g_backend ? po->t[ALL] : st->last_dev_s;
+    if (tpt < best) best = tpt;
   }
-  if (po->p > 1 && G.have_comm) { /* every rank must rank the points identically: max over ranks */
-    double *d = (double *)st->be->dmalloc(sizeof(double));
-    if (!d) return 99999999.0;
-    if (hipMemcpy(d, &best, sizeof best, hipMemcpyHostToDevice) != hipSuccess ||
-        R.AllReduce(d, d, 1, NCCL_FLOAT64, NCCL_MAX, G.world, (hipStream_t)st->s_compute) != 0 ||
-        hipStreamSynchronize((hipStream_t)st->s_compute) != hipSuccess ||
-        hipMemcpy(&best, d, sizeof best, hipMemcpyDeviceToHost) != hipSuccess)
-      best = 99999999.0;
-    st->be->dfree(d);
-  }
+  if (failed) best = 99999999.0;
+  (void)world_max(po, &best); /* every rank must rank the points identically */
   return best;
 }
 
-static void static_sweep(struct _offt_plan *po, void *user_buf) {
+/* the P1 lattice of the reference: divisors of p within [max(p/Nz', p/Ny, 1), min(Nx, Ny, p)]
+ * (params_range_setup, offt-compute.c:3002-3023) */
+static int p1_feasible(const struct _offt_plan *po, int d) {
+  const int Nzn = po->is_r2c ? po->Nz / 2 + 1 : po->Nz;
+  int pu = po->p < (po->Nx < po->Ny ? po->Nx : po->Ny) ? po->p : (po->Nx < po->Ny ? po->Nx : po->Ny);
+  int pl = po->p / Nzn > po->p / po->Ny ? po->p / Nzn : po->p / po->Ny;
+  if (pl < 1) pl = 1;
+  return d >= pl && d <= pu && po->p % d == 0;
+}
+
+/* switch the plan to mesh p1 x (p / p1): new decomposition, buffers and row / column communicators.  Collective. */
+static int mesh_rebuild(struct _offt_plan *po, int p1) {
+  hip_state *st = (hip_state *)po->hip_state;
+  mesh_teardown(st);
+  po->params->v[_P1_] = p1;
+  free(po->comm);
+  po->comm = comm_build(po);
+  return mesh_setup(po, st);
+}
+
+static void sweep_report(struct _offt_plan *po, double perf) {
+  if (po->rank) return;
+  db_append(po->point_database_file, po->params->v, perf);
+  printf("@ SWEEP %.5f ", perf);
+  print_params(po->params->v);
+}
+
+static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _offt_params *custom) {
   hip_state *st = (hip_state *)po->hip_state;
   int *v = po->params->v;
   const double t0 = wall_seconds();
@@ -728,18 +900,20 @@ static void static_sweep(struct _offt_plan *po, void *user_buf) {
   if (envdb) snprintf(po->point_database_file, sizeof po->point_database_file, "%s", envdb);
   else snprintf(po->point_database_file, sizeof po->point_database_file, "./tmp-db-%08d", (int)(getpid() % 100000000));
   if (!po->rank) printf("point_database_file %s\n", po->point_database_file);
-  void *buf = user_buf;
-  int own = 0;
-  if (!buf || !is_device_ptr(buf)) { /* tune on scratch: never stage a host array per point */
-    buf = st->be->dmalloc(local_elems(po->comm) * st->esz);
-    own = 1;
-    if (!buf) return;
-    (void)hipMemset(buf, 0, local_elems(po->comm) * st->esz);
-  }
   int best_v[PARAM_COUNT], points = 0, best_variant = -1;
   double best = 1e30;
-  memcpy(best_v, v, sizeof best_v);
+  void *buf = NULL;
+  int own = 0;
   if (!st->use_pipeline) {
+    if (g_backend) return; /* kernel variants exist on the GPU only */
+    buf = user_buf;
+    if (!buf || !is_device_ptr(buf)) { /* tune on scratch: never stage a host array per point */
+      buf = st->be->dmalloc(local_elems(po->comm) * st->esz);
+      own = 1;
+      if (!buf) return;
+      (void)hipMemset(buf, 0, local_elems(po->comm) * st->esz);
+    }
+    memcpy(best_v, v, sizeof best_v);
     int nv = offt_hipk_variant_count(po->Nx, st->prec);
     const int ny = offt_hipk_variant_count(po->Ny, st->prec), nz = offt_hipk_variant_count(po->Nz, st->prec);
     if (ny > nv) nv = ny;
@@ -753,59 +927,107 @@ static void static_sweep(struct _offt_plan *po, void *user_buf) {
       v[_Px1_] = e; v[_Py1_] = cols;
       for (int ax = 0; ax < 3; ax++) st->variant[ax] = var;
       double perf;
-      if (po->rank || !db_lookup(po->point_database_file, v, &perf)) {
-        perf = sweep_time_point(po, buf);
-        if (!po->rank) db_append(po->point_database_file, v, perf);
+      if (!db_lookup(po->point_database_file, v, &perf)) {
+        perf = sweep_time_point(po, buf, 0);
+        db_append(po->point_database_file, v, perf);
       }
-      if (!po->rank) { printf("@ SWEEP %.5f ", perf); print_params(v); }
+      printf("@ SWEEP %.5f ", perf); print_params(v);
       if (perf < best) { best = perf; best_variant = var; memcpy(best_v, v, sizeof best_v); }
     }
     for (int ax = 0; ax < 3; ax++) st->variant[ax] = best_variant;
-  } else if (st->slab_zyx) {
-    /* slab schedule: x-tile thickness T1 (message granularity of the exchange) x z-chunk
-     * thickness T2 (granularity of the overlapped FFTy/FFTx work) around the merged defaults */
-    const int T0 = st->sT, Z0 = st->sTz, M1 = po->comm->M1, M3 = po->comm->M3;
-    const int Tc[3] = {T0 / 2 > 0 ? T0 / 2 : 1, T0, 2 * T0 <= M1 ? 2 * T0 : M1};
-    const int Zc[3] = {Z0 / 2 > 0 ? Z0 / 2 : 1, Z0, 2 * Z0 <= M3 ? 2 * Z0 : M3};
-    st->t1_custom = st->t2_custom = 1;
-    v[_T1_] = T0; v[_T2_] = Z0;
-    memcpy(best_v, v, sizeof best_v);
-    for (int ti = 0; ti < 3 && points < po->max_loop; ti++) {
-      if (ti > 0 && Tc[ti] == Tc[ti - 1]) continue;
-      for (int zi = 0; zi < 3 && points < po->max_loop; zi++) {
-        if (zi > 0 && Zc[zi] == Zc[zi - 1]) continue;
-        v[_T1_] = Tc[ti]; v[_T2_] = Zc[zi];
-        slab_teardown(st);
-        if (slab_setup(po, st)) continue;
-        double perf = sweep_time_point(po, buf);
-        points++;
-        if (!po->rank) { db_append(po->point_database_file, v, perf); printf("@ SWEEP %.5f ", perf); print_params(v); }
-        if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
-      }
-    }
     memcpy(v, best_v, sizeof best_v);
-    slab_teardown(st);
-    (void)slab_setup(po, st);
   } else {
-    const int T0 = v[_T1_];
-    const int Tc[3] = {T0 / 2 > 0 ? T0 / 2 : 1, T0, 2 * T0 <= po->comm->M1 ? 2 * T0 : po->comm->M1};
-    const int Wc[3] = {1, 2, 3};
+    /* ---- stage A: mesh shape P1 in {1, the default divisor <= sqrt(p), p} (offt-compute.c:3002-3023 is the lattice the
+     * tuner searches, offt-tuning.c:879-992 rebuilds communicator, buffers and plans per point like mesh_rebuild) ---- */
+    int cand[3], nc = 0;
+    const int p1_now = v[_P1_];
+    if (custom && custom->v[_P1_] >= 0) cand[nc++] = p1_now; /* the caller fixed the mesh (-d) */
+    else {
+      const int want[3] = {p1_now, 1, po->p};
+      for (int i = 0; i < 3; i++) {
+        int dup = 0;
+        for (int j = 0; j < nc; j++) dup |= cand[j] == want[i];
+        if (!dup && p1_feasible(po, want[i])) cand[nc++] = want[i];
+      }
+      if (!nc) cand[nc++] = p1_now;
+    }
+    /* the scratch array must hold the local volume of every mesh tried (run-fft.c:270-288 sizes its array the same way) */
+    size_t need = local_elems(po->comm);
+    for (int i = 0; i < nc; i++) {
+      struct _offt_plan tmp = *po;
+      struct _offt_params tp = *po->params;
+      tmp.params = &tp; tp.v[_P1_] = cand[i];
+      struct _offt_comm *tc = comm_build(&tmp);
+      if (local_elems(tc) > need) need = local_elems(tc);
+      free(tc);
+    }
+    buf = st->be->dmalloc(need * st->esz);
+    own = 1;
+    int rc_buf = buf ? 0 : -1;
+    if (buf && !g_backend) (void)hipMemset(buf, 0, need * st->esz);
+    int best_p1 = p1_now;
+    for (int i = 0; i < nc && points < po->max_loop; i++, points++) {
+      int rc = rc_buf;
+      if (cand[i] != v[_P1_] && mesh_rebuild(po, cand[i])) rc = -1;
+      if (st->slab_zyx) { v[_T1_] = st->sT; v[_T2_] = st->sTz; } else { v[_T1_] = st->T; v[_T2_] = st->Tz2; }
+      const double perf = sweep_time_point(po, buf, rc);
+      sweep_report(po, perf);
+      if (perf < best) { best = perf; best_p1 = cand[i]; }
+    }
+    int rc_mesh = 0;
+    if (best_p1 != v[_P1_]) rc_mesh = mesh_rebuild(po, best_p1);
+    /* ---- stage B: tiling at that mesh.  slab: x-tile thickness T1 (message granularity of the exchange) x z-chunk
+     * thickness T2 (granularity of the overlapped FFTy/FFTx work); pencil: T1 x W1, then T2 -- around the defaults ---- */
+    st->t1_custom = st->t2_custom = 1;
+    const int M1 = po->comm->M1, M3 = po->comm->M3;
+    if (st->slab_zyx) { v[_T1_] = st->sT; v[_T2_] = st->sTz; } else { v[_T1_] = st->T; v[_T2_] = st->Tz2; }
+    memcpy(best_v, v, sizeof best_v);
+    const int T0 = v[_T1_], Z0 = v[_T2_];
+    const int Tc[3] = {T0, T0 / 2 > 0 ? T0 / 2 : 1, 2 * T0 <= M1 ? 2 * T0 : M1};
+    const int Zc[3] = {Z0, Z0 / 2 > 0 ? Z0 / 2 : 1, 2 * Z0 <= M3 ? 2 * Z0 : M3};
+    const int Wc[3] = {best_v[_W1_], best_v[_W1_] == 1 ? 2 : 1, 3};
     for (int ti = 0; ti < 3 && points < po->max_loop; ti++) {
-      if (ti > 0 && Tc[ti] == Tc[ti - 1]) continue;
-      for (int wi = 0; wi < 3 && points < po->max_loop; wi++, points++) {
-        v[_T1_] = Tc[ti]; v[_W1_] = Wc[wi];
+      if ((ti > 0 && Tc[ti] == Tc[0]) || (ti > 1 && Tc[ti] == Tc[1])) continue;
+      for (int zi = 0; zi < 3 && points < po->max_loop; zi++) {
+        if (ti == 0 && zi == 0) continue; /* the stage-A point */
+        if (st->slab_zyx) {
+          if ((zi > 0 && Zc[zi] == Zc[0]) || (zi > 1 && Zc[zi] == Zc[1])) continue;
+          v[_T1_] = Tc[ti]; v[_T2_] = Zc[zi];
+          slab_teardown(st);
+          const int rc = slab_setup(po, st) | rc_buf | rc_mesh;
+          const double perf = sweep_time_point(po, buf, rc);
+          points++;
+          sweep_report(po, perf);
+          if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
+        } else {
+          if ((zi > 0 && Wc[zi] == Wc[0]) || (zi > 1 && Wc[zi] == Wc[1])) continue;
+          v[_T1_] = Tc[ti]; v[_W1_] = Wc[zi];
+          ring_teardown(st);
+          const int rc = ring_setup(po, st) | rc_buf | rc_mesh;
+          const double perf = sweep_time_point(po, buf, rc);
+          points++;
+          sweep_report(po, perf);
+          if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
+        }
+      }
+    }
+    if (!st->slab_zyx) { /* pencil: phase-2 chunk thickness at the best (T1, W1) */
+      for (int zi = 1; zi < 3 && points < po->max_loop; zi++) {
+        if (Zc[zi] == Zc[0] || (zi > 1 && Zc[zi] == Zc[1])) continue;
+        memcpy(v, best_v, sizeof best_v);
+        v[_T2_] = Zc[zi];
         ring_teardown(st);
-        if (ring_setup(po, st)) { v[_T1_] = best_v[_T1_]; v[_W1_] = best_v[_W1_]; continue; }
-        double perf = sweep_time_point(po, buf);
-        if (!po->rank) { db_append(po->point_database_file, v, perf); printf("@ SWEEP %.5f ", perf); print_params(v); }
+        const int rc = ring_setup(po, st) | rc_buf | rc_mesh;
+        const double perf = sweep_time_point(po, buf, rc);
+        points++;
+        sweep_report(po, perf);
         if (perf < best) { best = perf; memcpy(best_v, v, sizeof best_v); }
       }
     }
     memcpy(v, best_v, sizeof best_v);
-    ring_teardown(st);
-    (void)ring_setup(po, st);
+    if (st->slab_zyx) { slab_teardown(st); (void)slab_setup(po, st); }
+    else { ring_teardown(st); (void)ring_setup(po, st); }
   }
-  memcpy(v, best_v, sizeof best_v);
   po->params->is_converged = 1;
   if (own) st->be->dfree(buf);
   po->t_init[INIT_AH] = wall_seconds() - t0;
@@ -836,6 +1058,7 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream) {
 }
 void offt_hip_set_output_scale(struct _offt_plan *po, double scale) { ((hip_state *)po->hip_state)->out_scale = scale; }
 void offt_hip_set_async(struct _offt_plan *po, int async) { ((hip_state *)po->hip_state)->async = async; }
+void offt_hip_set_debug_skip(struct _offt_plan *po, int mask) { ((hip_state *)po->hip_state)->skip_mask = mask; }
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
 }
@@ -1010,6 +1233,7 @@ static void rec_free(step_list *l) {
 }
 
 static int run_pass(hip_state *st, const offt_pass_desc *d, const void *src, void *dst, void *stream, int first) {
+  if (st->skip_mask & 1) return 0; /* diagnostics: exchange-only timing */
   if (!st->rec) return st->be->pass(d, src, dst, stream);
   step *e = rec_new(st->rec);
   e->kind = 0; e->first = first; e->d = *d; e->src = src; e->dst = dst;
@@ -1017,6 +1241,7 @@ static int run_pass(hip_state *st, const offt_pass_desc *d, const void *src, voi
 }
 static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const void *const *sp, const size_t *sb,
                    void *const *rp, const size_t *rb, void *stream) {
+  if (st->skip_mask & 2) return 0; /* diagnostics: compute-only timing */
   if (!st->rec) return st->be->a2a(st, which, cnt, peer, sp, sb, rp, rb, stream);
   step *e = rec_new(st->rec);
   e->kind = 1; e->which = which; e->cnt = cnt;
@@ -1233,18 +1458,26 @@ static int execute_slab(struct _offt_plan *po, void *data) {
 /* ------------------------------------------------------------------------- */
 /* tile pipeline for p1 x p2 ranks (forward)                                  */
 /*                                                                           */
-/* reference:  for each x-tile i:  FFTz+pack1(i); wait(i-W); ia2a(i);        */
-/*             unpack1+FFTy(i-W)            (offt-compute.c:3537-3679)       */
-/*             [transpose]; for each z-tile j: FFTy+pack2(j); ... FFTx       */
-/* here:       for each x-tile i:  K1(i) = FFTz storing straight into the    */
-/*             per-peer send blocks; a2a1(i) on comm stream 1; K2(i-W) =     */
-/*             FFTy loading straight from the receive blocks and storing     */
-/*             into the column-exchange blocks; a2a2(i-W) on comm stream 2.  */
-/*             Then K3 = FFTx loading from the received column blocks and    */
-/*             storing in the caller's output layout (ostride).              */
-/* Both exchanges are tiled along x (T1/W1); T2/W2 are accepted but unused:  */
-/* with the second exchange streaming behind the first there is no separate  */
-/* phase 2 loop.  Three HBM round trips per element in total.                */
+/* reference:  phase 1, for each x-tile i (T1 planes, window W1):            */
+/*               FFTz+pack1(i); wait(i-W); ia2a(i); unpack1+FFTy(i-W)        */
+/*                                           (offt-compute.c:3537-3679)      */
+/*             [transpose]; phase 2, for each z-tile h (T2 planes, W2):      */
+/*               FFTy+pack2(h); wait; ia2a(h); unpack2+FFTx(h-W)             */
+/*                                           (offt-compute.c:3682-3862)      */
+/* here:       phase 1, for each x-tile i: K1(i) = FFTz storing straight     */
+/*             into the per-peer send blocks; a2a1(i) over the row group;    */
+/*             K2(i-W) = FFTy loading straight from the receive blocks and   */
+/*             storing into the column-exchange volume, which is laid out    */
+/*             per peer as [z-chunk h][x][y_l][z in chunk] (T2 planes per    */
+/*             chunk); a2a2(i-W): x-tile i-W of every z-chunk over the       */
+/*             column group, so exchange 2 streams behind exchange 1.        */
+/*             phase 2, for each z-chunk h: K3(h) = FFTx loading from the    */
+/*             received column blocks of chunk h and storing in the caller's */
+/*             output layout -- launched as soon as the LAST x-tile's share  */
+/*             of chunk h has arrived, i.e. under the rest of exchange 2.    */
+/* Exposed at the end: the last chunk's FFTx only (W2 = 0, the reference's   */
+/* blocking mode, waits for the whole exchange instead).  Three HBM round    */
+/* trips per element in total.                                               */
 /* ------------------------------------------------------------------------- */
 
 static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
@@ -1253,11 +1486,15 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   const struct _offt_comm *c = po->comm;
   const int p1 = c->p1, p2 = c->p2, T = st->T, W = st->ring - 1;
   const int Nx = po->Nx, Ny = po->Ny, Nz = po->Nz;
+  const int Tz = st->Tz2, H = st->H2;
   const size_t esz = st->esz;
+  const size_t MM = (size_t)c->M1 * c->M4; /* elements per z-plane of a peer block of exchange 2 */
   void *s = st->s_compute;
   int peers1[p2 > 0 ? p2 : 1], peers2[p1 > 0 ? p1 : 1];
   for (int a = 0; a < p2; a++) peers1[a] = a; /* key = rank_y inside comm1 */
   for (int a = 0; a < p1; a++) peers2[a] = a; /* key = rank_x inside comm2 */
+  const int Hf = c->m3 / Tz;                   /* chunks whose Tz planes are all owned by this rank */
+  const int w2 = po->params->v[_W2_];
 
   /* One in-order compute stream carries the reference's software pipeline
    * "pack(i); wait(i-W); ia2a(i); unpack(i-W)" (offt-compute.c:3537-3647): K1(i) then
@@ -1306,61 +1543,84 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
       if (st->x1) be->stream_wait(s, st->ev_a1[r]);
-      if (myT > 0 && c->m3 > 0) {
+      for (int part = 0; part < 2 && myT > 0; part++) {
+        /* the chunks this rank fills completely go in one launch (chunk = second batch dimension), the ragged last
+         * chunk (m3 not a multiple of T2) in another */
+        const int h0 = part == 0 ? 0 : Hf, nh = part == 0 ? Hf : (c->m3 > Hf * Tz ? 1 : 0);
+        if (!nh) continue;
+        const int z0 = h0 * Tz;
+        int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;                   /* planes of the chunk in the (padded) layout */
+        const int nz = part == 0 ? Tz : c->m3 - z0;                    /* ... of which this rank owns nz */
         offt_pass_desc d;
         desc_init(&d, st, Ny, dir, 1);
-        void *k2dst;
-        d.ncols = c->m3; d.nb1 = myT;
-        d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3;
-        d.out_axis_stride = c->M3; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M3;
-        if (p1 > 1) {
-          d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
-          d.out_block_stride = (long long)st->blk2;
-        }
-        k2dst = (char *)st->send2 + (size_t)x0 * c->M4 * c->M3 * esz;
+        d.ncols = nz; d.nb1 = myT; d.nb2 = nh;
+        d.in_axis_stride = c->M3; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * c->M3; d.in_b2_stride = Tz;
         if (p2 > 1) {
           d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0;
           d.in_block_stride = (long long)st->blk1;
         }
-        if (run_pass(st, &d, st->recv1[r], k2dst, s, 0)) return -1;
+        d.out_axis_stride = tzh; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * tzh;
+        d.out_b2_stride = (long long)MM * Tz;
+        if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
+          d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
+          d.out_block_stride = (long long)st->blk2;
+        }
+        if (run_pass(st, &d, (char *)st->recv1[r] + (size_t)z0 * esz,
+                     (char *)st->send2 + ((size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz, s, 0)) return -1;
       }
       be->event_record(st->ev_k2[r], s);
-      /* ---- a2a2(k) over comm2: x-tile k of every column block ---- */
+      /* ---- a2a2(k) over comm2: x-tile k of every z-chunk of every column block.  All chunks of a tile go in one
+       * grouped call, except for the last tile: there each chunk is its own call with an event behind it, so that
+       * K3(h) can start while chunks h+1.. are still on the wire ---- */
       if (st->x2) {
         be->stream_wait(st->s_comm2, st->ev_k2[r]);
-        const void *sp[p1]; void *rp[p1]; size_t sb[p1], rb[p1];
-        int any = 0;
-        for (int a = 0; a < p1; a++) {
-          int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
-          sp[a] = (char *)st->send2 + ((size_t)a * st->blk2 + (size_t)x0 * c->M4 * c->M3) * esz;
-          rp[a] = (char *)st->recv2 + ((size_t)a * st->blk2 + (size_t)x0 * c->M4 * c->M3) * esz;
-          sb[a] = (size_t)myT * c->M4 * c->M3 * esz;
-          rb[a] = (size_t)ma * c->M4 * c->M3 * esz;
-          any |= (sb[a] || rb[a]);
+        const int last = (k == st->ntiles - 1);
+        const int ngroups = last ? H : 1, per = last ? 1 : H;
+        for (int g = 0; g < ngroups; g++) {
+          const int cnt = per * p1;
+          const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
+          int any = 0;
+          for (int hh = 0; hh < per; hh++) {
+            const int h = last ? g : hh, z0 = h * Tz;
+            int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
+            for (int a = 0; a < p1; a++) {
+              const int e = hh * p1 + a;
+              int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
+              const size_t off = ((size_t)a * st->blk2 + (size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz;
+              pr[e] = peers2[a];
+              sp[e] = (char *)st->send2 + off;
+              rp[e] = (char *)st->recv2 + off;
+              sb[e] = (size_t)myT * c->M4 * tzh * esz;
+              rb[e] = (size_t)ma * c->M4 * tzh * esz;
+              any |= (sb[e] || rb[e]);
+            }
+          }
+          if (any && run_a2a(st, 2, cnt, pr, sp, sb, rp, rb, st->s_comm2)) return -1;
+          if (last) be->event_record(st->ev_a2[g], st->s_comm2);
         }
-        if (any && run_a2a(st, 2, p1, peers2, sp, sb, rp, rb, st->s_comm2)) return -1;
       }
     }
   }
-  if (st->x2) {
-    be->event_record(st->ev_a2_last, st->s_comm2);
-    be->stream_wait(s, st->ev_a2_last);
-  }
   be->event_record(st->evp[2], s);
-  /* ---- K3: unpack2 + FFTx into the caller's layout (offt-compute.c:2347-2993) ---- */
-  if (c->m4 > 0 && c->m3 > 0) {
+  /* ---- K3(h): unpack2 + FFTx into the caller's layout (offt-compute.c:2347-2993), z-chunk by z-chunk ---- */
+  for (int h = 0; h < H; h++) {
+    const int z0 = h * Tz;
+    int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
+    int nz = c->m3 - z0; if (nz > tzh) nz = tzh;
+    if (st->x2) be->stream_wait(s, st->ev_a2[w2 == 0 ? H - 1 : h]);
+    if (nz <= 0 || c->m4 <= 0) continue;
     offt_pass_desc d;
     desc_init(&d, st, Nx, dir, 0);
-    d.ncols = c->m3; d.nb1 = c->m4;
-    d.in_axis_stride = (long long)c->M4 * c->M3; d.in_col_stride = 1; d.in_b1_stride = c->M3;
-    if (p1 > 1) {
+    d.ncols = nz; d.nb1 = c->m4;
+    d.in_axis_stride = (long long)c->M4 * tzh; d.in_col_stride = 1; d.in_b1_stride = tzh;
+    if (p1 > 1) { /* peer a owns x in [a*F1, ..): offt-compute.c:2432-2450 */
       d.in_split = c->F1; d.in_split_nfloor = c->b1 ? p1 - c->b1 : 0;
       d.in_block_stride = (long long)st->blk2;
     }
     d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
     d.out_contig = (c->ostride[0] == 1);
     d.scale = st->out_scale;
-    if (run_pass(st, &d, st->recv2, data, s, 0)) return -1;
+    if (run_pass(st, &d, (char *)st->recv2 + (size_t)z0 * MM * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
   }
   be->event_record(st->evp[3], s);
   return 0;
@@ -1369,15 +1629,74 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
 /* ------------------------------------------------------------------------- */
 /* execute (offt-compute.c:3864-4048)                                         */
 /* ------------------------------------------------------------------------- */
+/* a communicator of this plan (or the world) reported an asynchronous error, or a wait ran out of time: abort the
+ * communicators so that their kernels leave the GPU, and make every later call fail fast.  The reference has no failure
+ * path here at all -- communicate_wait (offt-compute.c:883-890) sits in MPI_Wait forever when a peer dies. */
+static void comm_fail(hip_state *st) {
+  G.comm_failed = 1;
+  if (R.CommAbort) {
+    if (st->have_comm1) { (void)R.CommAbort(st->comm1); st->have_comm1 = 0; }
+    if (st->have_comm2) { (void)R.CommAbort(st->comm2); st->have_comm2 = 0; }
+    if (G.have_comm) { (void)R.CommAbort(G.world); G.have_comm = 0; G.world = NULL; }
+  }
+  st->comm1 = st->comm2 = NULL;
+}
+
+static int comm_async_error(hip_state *st) {
+  if (!R.CommGetAsyncError) return 0;
+  ncclComm_t cs[3] = {G.have_comm ? G.world : NULL, st->have_comm1 ? st->comm1 : NULL, st->have_comm2 ? st->comm2 : NULL};
+  for (int i = 0; i < 3; i++) {
+    ncclResult_t ar = 0;
+    if (!cs[i]) continue;
+    if (R.CommGetAsyncError(cs[i], &ar) != 0 || (ar != 0 && ar != NCCL_IN_PROGRESS)) {
+      SET_ERR("RCCL communicator %d reported an asynchronous error: %s", i, R.GetErrorString(ar));
+      return -1;
+    }
+  }
+  return 0;
+}
+
+/* wait for the compute stream.  A plan that exchanges over RCCL polls instead of blocking: every millisecond the
+ * communicators are asked for asynchronous errors, and the wait is bounded (OFFT_EXEC_TIMEOUT seconds, default 120) --
+ * a dead or stuck peer becomes the failure marker t[ALL] = 99999999 plus offt_hip_last_error(), not a hang. */
+static int wait_compute(hip_state *st) {
+  if (!st->uses_rccl) return st->be->stream_sync(st->s_compute);
+  const double limit = getenv("OFFT_EXEC_TIMEOUT") ? atof(getenv("OFFT_EXEC_TIMEOUT")) : 120.0;
+  const double t0 = wall_seconds();
+  double tchk = t0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery((hipStream_t)st->s_compute);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { SET_ERR("compute stream failed: %s", hipGetErrorString(q)); comm_fail(st); return -1; }
+    const double now = wall_seconds();
+    if (now - tchk < 1e-3) continue;
+    tchk = now;
+    if (comm_async_error(st)) { comm_fail(st); return -1; }
+    if (now - t0 > limit) {
+      SET_ERR("offt_3d_execute: no completion after %.0f s (a peer is missing or an exchange is stuck); communicators aborted", limit);
+      comm_fail(st);
+      return -1;
+    }
+  }
+  if (comm_async_error(st)) { comm_fail(st); return -1; }
+  return 0;
+}
+
 void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int direction) {
   hip_state *st = (hip_state *)po->hip_state;
   const offt_backend *be = st->be;
   double *t = po->t;
   memset(t, 0, GES * sizeof(double));
+  TEST_NOTE_MESH(po);
   if (in != out && !st->warned_in) {
     /* offt-compute.c:3866: "in must be equal to out" -- the reference silently ignores `in` */
     fprintf(stderr, "offt(hip): offt_3d_execute is in-place; `in` is ignored (as in the reference)\n");
     st->warned_in = 1;
+  }
+  if (st->uses_rccl && G.comm_failed) {
+    SET_ERR("offt_3d_execute: the communicator failed earlier; make a new world (offt_hip_set_world) and plan");
+    t[ALL] = 99999999.0;
+    return;
   }
   double t0 = wall_seconds();
   void *data = out;
@@ -1399,9 +1718,13 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
   else if (direction > 0) rc = execute_inverse_multi(po, data);
   else rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, direction);
   if (timed) be->event_record(st->ev1, st->s_compute);
-  if (rc) { t[ALL] = 99999999.0; return; } /* the reference's failure marker, offt-compute.c:3881 */
+  if (rc) { /* the reference's failure marker, offt-compute.c:3881 */
+    if (st->uses_rccl) comm_fail(st); /* peers may already sit in an exchange this rank will never join */
+    t[ALL] = 99999999.0;
+    return;
+  }
   if (st->async && !staged) { t[ALL] = wall_seconds() - t0; return; }
-  if (be->stream_sync(st->s_compute)) { t[ALL] = 99999999.0; return; }
+  if (wait_compute(st)) { t[ALL] = 99999999.0; return; }
   st->last_dev_s = 1e-3 * be->event_ms(st->ev0, st->ev1);
   double a = 1e-3 * be->event_ms(st->evp[0], st->evp[1]);
   double b = 1e-3 * be->event_ms(st->evp[1], st->evp[2]);
@@ -1455,4 +1778,69 @@ int offt_hip_fill_input(struct _offt_plan *po, void *buf, int kind) {
                         c->istart[2], c->istride[0], c->istride[1], c->istride[2], st->s_compute);
   if (rc) { SET_ERR("%s", offt_hipk_last_error()); return rc; }
   return st->be->stream_sync(st->s_compute);
+}
+
+/* ------------------------------------------------------------------------- */
+/* xGMI link probe: grouped ncclSend/ncclRecv on the world communicator, the   */
+/* exact primitive of the exchanges above, timed with HIP events.              */
+/*   mode 0  all-to-all: every rank sends `bytes` to every other rank          */
+/*   mode 1  shift: rank r sends `bytes` to (r + shift) % size and receives    */
+/*           from (r - shift) % size -- one link per direction                 */
+/* Returns this rank's seconds per repetition (the caller takes the max over   */
+/* ranks), negative on failure.  SURVEY.md 7 hard part #1: decide mesh shapes   */
+/* with a measured link number, not a data-sheet one.                           */
+/* ------------------------------------------------------------------------- */
+double offt_hip_link_probe(int mode, int shift, long long bytes, int reps) {
+  if (!G.have_comm || G.comm_failed) { SET_ERR("offt_hip_link_probe: no world communicator"); return -1.0; }
+  if (bytes < 1 || reps < 1) { SET_ERR("offt_hip_link_probe: bad arguments"); return -1.0; }
+  const int p = G.size, me = G.rank;
+  const int npeer = mode == 0 ? p : 1;
+  char *sbuf = NULL, *rbuf = NULL;
+  hipStream_t s = NULL;
+  hipEvent_t e0 = NULL, e1 = NULL;
+  double result = -1.0;
+  if (hipMalloc((void **)&sbuf, (size_t)bytes * npeer) != hipSuccess || hipMalloc((void **)&rbuf, (size_t)bytes * npeer) != hipSuccess ||
+      hipMemset(sbuf, 1, (size_t)bytes * npeer) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    SET_ERR("offt_hip_link_probe: allocation failed");
+    goto done;
+  }
+  for (int r = -1; r < reps; r++) { /* r = -1: warm-up (connection set-up), not timed */
+    if (r == 0 && hipEventRecord(e0, s) != hipSuccess) goto done;
+    NCHECK(R.GroupStart(), goto done);
+    if (mode == 0) {
+      for (int a = 0; a < p; a++) {
+        if (a == me) continue;
+        NCHECK(R.Send(sbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), goto done);
+        NCHECK(R.Recv(rbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), goto done);
+      }
+    } else {
+      const int to = (me + shift % p + p) % p, from = (me - shift % p + p) % p;
+      if (to != me) {
+        NCHECK(R.Send(sbuf, (size_t)bytes, NCCL_INT8, to, G.world, s), goto done);
+        NCHECK(R.Recv(rbuf, (size_t)bytes, NCCL_INT8, from, G.world, s), goto done);
+      }
+    }
+    NCHECK(R.GroupEnd(), goto done);
+  }
+  if (hipEventRecord(e1, s) != hipSuccess) goto done;
+  {
+    /* bounded wait, like an execute */
+    const double t0 = wall_seconds();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady || wall_seconds() - t0 > 60.0) { SET_ERR("offt_hip_link_probe: exchange did not complete"); goto done; }
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) goto done;
+    result = 1e-3 * ms / reps;
+  }
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (s) (void)hipStreamDestroy(s);
+  if (sbuf) (void)hipFree(sbuf);
+  if (rbuf) (void)hipFree(rbuf);
+  return result;
 }

@@ -18,13 +18,13 @@ def main():
     import cpu_world
     from offt_amd import api
     for ci, case in enumerate(cfg):
-        p1 = case["params"].get("P1")
-        if p1 is None:
-            import oracle_lib as O
-            p1 = O.params_default(case["N"][0], case["N"][1], case["N"][2], size)[0]
-        cpu_world.install(rank, size, p1=p1, dist=dist)
+        for k, v in case.get("env", {}).items():
+            os.environ[k] = str(v).replace("{outdir}", outdir)
+        cpu_world.install(rank, size, dist=dist)
         res = cpu_world.run_rank(*case["N"], kind=1, is_equalxy=case.get("eq", 0), is_r2c=case.get("r2c", 0),
-                                 roundtrip=bool(case.get("inv")), **case["params"])
+                                 roundtrip=bool(case.get("inv")), max_loop=case.get("max_loop", 0), **case["params"])
+        for k in case.get("env", {}):
+            os.environ.pop(k, None)
         c, v, buf = res[:3]
         np.save(os.path.join(outdir, f"case{ci}_rank{rank}.npy"), buf)
         if case.get("inv"):

@@ -20,20 +20,17 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=size)
     torch.cuda.set_device(0)
     import oracle_lib as O
+    import cpu_world
     from cpu_world import A2A_CB
     from offt_amd import api
-    L = api.lib()
-    L.offt_hip_test_set_transport.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L = cpu_world.test_lib()  # the build with the test-only transport seam; same kernels and host code as the product
     state = {"p1": 1}
 
     def transport(which, npeers, peer_in_group, sendp, sendbytes, recvp, recvbytes):
         try:
-            p2 = size // state["p1"]
-            rx, ry = rank // p2, rank % p2
             reqs, pend = [], []
             for a in range(npeers):
-                g = peer_in_group[a]
-                peer = rx * p2 + g if which == 1 else g * p2 + ry
+                peer = cpu_world.group_peer(which, peer_in_group[a], rank, size, L.offt_hip_test_current_p1())
                 sb, rb = sendbytes[a], recvbytes[a]
                 if peer == rank:
                     if sb:

@@ -18,7 +18,7 @@ def built():
     """Make sure the product library and the oracle are built (hipcc cross-compiles without a GPU)."""
     import subprocess
     need = [os.path.join(ROOT, "offt_amd", "liboffthip.so"), os.path.join(ROOT, "oracle", "liboracle.so"),
-            os.path.join(ROOT, "tests", "libcpubackend.so")]
+            os.path.join(ROOT, "tests", "libcpubackend.so"), os.path.join(ROOT, "tests", "liboffthip_test.so")]
     if not all(os.path.exists(n) for n in need):
-        subprocess.check_call(["make", "-C", ROOT, "all", "tests/libcpubackend.so"])
+        subprocess.check_call(["make", "-C", ROOT, "all", "tests/libcpubackend.so", "tests/liboffthip_test.so"])
     return True

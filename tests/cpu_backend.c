@@ -10,6 +10,7 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "offt_backend.h"
 #include "oracle.h"
 
@@ -63,12 +64,18 @@ static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
 }
 static void *cb_stream_create(void) { return malloc(8); }
 static void cb_stream_destroy(void *s) { free(s); }
-static void *cb_event_create(void) { return malloc(8); }
+static void *cb_event_create(void) { return calloc(1, sizeof(double)); }
 static void cb_event_destroy(void *e) { free(e); }
-static int cb_event_record(void *e, void *s) { (void)e; (void)s; return 0; }
+static int cb_event_record(void *e, void *s) { /* everything runs synchronously: an event is a wall-clock stamp */
+  (void)s;
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  if (e) *(double *)e = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+  return 0;
+}
 static int cb_stream_wait(void *s, void *e) { (void)e; (void)s; return 0; }
 static int cb_stream_sync(void *s) { (void)s; return 0; }
-static double cb_event_ms(void *a, void *b) { (void)a; (void)b; return 0.0; }
+static double cb_event_ms(void *a, void *b) { return (a && b) ? *(double *)b - *(double *)a : 0.0; }
 static int cb_a2a(void *ctx, int which, int npeers, const int *peer, const void *const *sendp, const size_t *sendbytes,
                   void *const *recvp, const size_t *recvbytes, void *stream) {
   (void)ctx; (void)stream;

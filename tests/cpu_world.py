@@ -12,6 +12,9 @@ import oracle_lib as O
 from offt_amd import api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the TEST build of the library: same kernel objects, host compiled with -DOFFT_TEST_SEAMS (Makefile); the product
+# library offt_amd/liboffthip.so carries neither offt_hip_test_set_backend nor offt_hip_test_set_transport
+TEST_LIB = os.environ.get("OFFT_AMD_TEST_LIB") or os.path.join(ROOT, "tests", "liboffthip_test.so")
 A2A_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _keep = {}
@@ -28,21 +31,45 @@ def _cb_lib():
     return L
 
 
-def install(rank=0, size=1, p1=None, dist=None):
-    """Install the CPU backend into liboffthip.so for (rank, size)."""
-    CB = _cb_lib()
-    L = api.lib()
+def test_lib():
+    """route offt_amd.api through the test build (api.use_library(None) goes back to the product)"""
+    if not os.path.exists(TEST_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-C", ROOT, "tests/liboffthip_test.so"])
+    L = api.use_library(TEST_LIB)
     L.offt_hip_test_set_backend.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.offt_hip_test_set_backend.restype = None
+    L.offt_hip_test_set_transport.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.offt_hip_test_set_transport.restype = None
+    return L
+
+
+def group_peer(which, g, rank, size, p1):
+    """world rank of member g of exchange group `which` as seen from `rank`: 1 = row group (p2 ranks sharing rank_x),
+    2 = column group (p1 ranks sharing rank_y), 0 = the whole world (offt_backend.h)"""
+    p2 = size // p1 if p1 else size
+    rx, ry = rank // p2, rank % p2
+    return g if which == 0 else (rx * p2 + g if which == 1 else g * p2 + ry)
+
+
+def install(rank=0, size=1, p1=None, dist=None, fail_after=None):
+    """Install the CPU backend into the test build of the library for (rank, size).  The mesh shape is asked from
+    the library per exchange (offt_hip_test_current_p1; `p1` is kept for callers that pass it); fail_after = N makes
+    the N-th exchange fail (communication-failure tests)."""
+    CB = _cb_lib()
+    L = test_lib()
+    calls = {"n": 0}
 
     def a2a(which, npeers, peer_in_group, sendp, sendbytes, recvp, recvbytes):
         try:
             import torch
-            p2 = size // p1 if p1 else size
-            rx, ry = rank // p2, rank % p2
+            calls["n"] += 1
+            if fail_after is not None and calls["n"] >= fail_after:
+                return -1
+            cur_p1 = L.offt_hip_test_current_p1()
             reqs, keep = [], []
             for a in range(npeers):
-                g = peer_in_group[a]  # rank inside the row (which == 1) / column (which == 2) group
-                peer = rx * p2 + g if which == 1 else g * p2 + ry
+                peer = group_peer(which, peer_in_group[a], rank, size, cur_p1)
                 sb, rb = sendbytes[a], recvbytes[a]
                 if peer == rank:
                     assert sb == rb
@@ -74,15 +101,16 @@ def install(rank=0, size=1, p1=None, dist=None):
 
 
 def uninstall():
-    L = api.lib()
-    L.offt_hip_test_set_backend.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L = test_lib()
     L.offt_hip_test_set_backend(None, 0, 1)
+    api.use_library(None)
 
 
-def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, is_r2c=0, roundtrip=False, **params):
+def run_rank(Nx, Ny, Nz, kind=1, is_equalxy=0, precision=api.F64, direction=-1, is_r2c=0, roundtrip=False, max_loop=0, **params):
     """init + fill this rank's block on the host + execute; returns (comm dict, params, local result array)."""
     cp = api.make_params(**params)
-    po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision, is_r2c=is_r2c)
+    po = api.offt_3d_init(Nx, Ny, Nz, custom_params=cp, is_equalxy=is_equalxy, precision=precision, is_r2c=is_r2c,
+                          max_loop=max_loop)
     c = api.comm_dict(po)
     v = list(po.contents.params.contents.v)
     n = api.local_elems(po)

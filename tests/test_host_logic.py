@@ -1,6 +1,7 @@
 """CPU tests of the PRODUCT's host logic (offt_host.c) with the GPU operations swapped for the
 test-only CPU interpreter: decomposition, defaults, pass descriptors, tile ring, exchange schedule.
 Multi-rank cases run as real processes over `gloo` (world_size 2 and 4)."""
+import ctypes as C
 import json
 import os
 import socket
@@ -163,7 +164,10 @@ def _run_world(size, cases, tmp_path):
         want = np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2)) if r2c else np.fft.fftn(O.hash_field(*shape))
         assert rel(G, want) < TOL, case
         # and against the restated reference pipeline on the same decomposition
-        og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **case["params"])
+        oparams = dict(case["params"])
+        if case.get("max_loop"):  # the static sweep chose the mesh: the oracle runs on the mesh the plan ended up with
+            oparams["P1"] = json.load(open(tmp_path / f"case{ci}_rank0.json"))["v"][0]
+        og, _, _ = O.world_fft(*shape, size, kind=1, is_equalxy=case.get("eq", 0), is_r2c=r2c, **oparams)
         assert rel(G, og) < TOL, case
         if case.get("inv"):  # offt_3d_execute_dir(+1) on the result gives back every rank's input block * N
             for r in range(size):
@@ -186,15 +190,45 @@ def test_gloo_world2(built, tmp_path):
              dict(N=[7, 5, 11], params=dict(P1=1, T1=2, T2=4), r2c=1),
              # multi-rank inverse (extension): slab and pencil schedules replayed backwards
              dict(N=[8, 8, 8], params=dict(P1=1), inv=1), dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2), inv=1),
-             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=1), inv=1), dict(N=[9, 7, 5], params=dict(P1=2, S=1), inv=1)]
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=1), inv=1), dict(N=[9, 7, 5], params=dict(P1=2, S=1), inv=1),
+             # pencil schedule, phase 2 in z-chunks of T2 planes (offt-compute.c:3682-3862): several chunks, a ragged
+             # last chunk, W2 = 0 (no overlap), every output layout, r2c, inverse replay
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=1, T2=2)), dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3)),
+             dict(N=[9, 7, 11], params=dict(P1=2, T1=4, T2=4, W2=0, S=1)), dict(N=[8, 8, 10], params=dict(P1=2, T2=3), eq=1),
+             dict(N=[8, 6, 12], params=dict(P1=2, T1=3, T2=2), r2c=1), dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3), inv=1),
+             dict(N=[9, 7, 11], params=dict(P1=1, T1=2, T2=3, S=1)),
+             # the defaults' own tiling (no 4 MiB message floor): T1 = M1/16, T2 = M3/16 merged to <= 8 chunks
+             dict(N=[32, 16, 32], params=dict(P1=2), env=dict(OFFT_MIN_MSG=0)),
+             dict(N=[32, 16, 32], params=dict(P1=1), env=dict(OFFT_MIN_MSG=0))]
     _run_world(2, cases, tmp_path)
 
 
 def test_gloo_world4(built, tmp_path):
     cases = [dict(N=[8, 8, 8], params=dict(P1=2)), dict(N=[8, 8, 8], params=dict(P1=4, S=1)),
              dict(N=[8, 8, 8], params=dict(P1=1, T1=3)), dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1)),
-             dict(N=[6, 10, 7], params=dict(P1=2, S=1))]
+             dict(N=[6, 10, 7], params=dict(P1=2, S=1)),
+             dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1, T2=2)), dict(N=[12, 8, 10], params=dict(P1=4, T1=1, T2=3)),
+             dict(N=[10, 6, 9], params=dict(P1=2, T1=2, T2=2), inv=1), dict(N=[16, 16, 16], params=dict(), env=dict(OFFT_MIN_MSG=0))]
     _run_world(4, cases, tmp_path)
+
+
+def test_gloo_world4_static_sweep_with_mesh(built, tmp_path):
+    """max_loop > 0 on several ranks: the sweep tries the meshes P1 in {default, 1, p} (rebuilding decomposition,
+    buffers and groups per point like offt-tuning.c:929), then tilings; every point is timed as a max over ranks, so
+    all ranks must end on the SAME point; rank 0 logs `perf v0..v23` lines (offt-tuning.c:231-277)."""
+    cases = [dict(N=[16, 16, 16], params=dict(), max_loop=7, env=dict(OFFT_SWEEP_DB="{outdir}/sweep.db", OFFT_MIN_MSG=0)),
+             dict(N=[12, 8, 10], params=dict(P1=2), max_loop=3, env=dict(OFFT_SWEEP_DB="{outdir}/sweep2.db"))]
+    _run_world(4, cases, tmp_path)
+    vs = [json.load(open(tmp_path / f"case0_rank{r}.json"))["v"] for r in range(4)]
+    assert all(v == vs[0] for v in vs), vs
+    lines = [ln.split() for ln in open(tmp_path / "sweep.db").read().splitlines()]
+    assert len(lines) == 7 and all(len(ln) == 25 for ln in lines)
+    assert sorted({int(ln[1]) for ln in lines[:3]}) == [1, 2, 4]            # stage A: the three meshes
+    assert len({int(ln[1]) for ln in lines[3:]}) == 1                       # stage B stays on the winner
+    assert vs[0][0] == int(lines[3][1])
+    vs2 = [json.load(open(tmp_path / f"case1_rank{r}.json"))["v"] for r in range(4)]
+    assert all(v == vs2[0] for v in vs2) and vs2[0][0] == 2                 # -d given: the mesh is not swept
+    assert {int(ln.split()[1]) for ln in open(tmp_path / "sweep2.db").read().splitlines()} == {2}
 
 
 def test_gloo_world8(built, tmp_path):
@@ -203,8 +237,35 @@ def test_gloo_world8(built, tmp_path):
              dict(N=[16, 16, 16], params=dict(P1=8)), dict(N=[16, 16, 16], params=dict(P1=1, S=1, T1=4)),
              dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1)), dict(N=[16, 16, 16], params=dict(P1=1), r2c=1),
              dict(N=[16, 16, 16], params=dict(P1=4), eq=1), dict(N=[16, 16, 16], params=dict(P1=1), inv=1),
-             dict(N=[16, 16, 16], params=dict(), inv=1)]
+             dict(N=[16, 16, 16], params=dict(), inv=1),
+             dict(N=[16, 16, 16], params=dict(T1=2, T2=1)), dict(N=[20, 12, 18], params=dict(P1=2, T1=3, W1=1, T2=2)),
+             dict(N=[16, 16, 16], params=dict(P1=8, T1=1, T2=4)), dict(N=[16, 16, 16], params=dict(P1=4, T2=2), inv=1)]
     _run_world(8, cases, tmp_path)
+
+
+def test_exchange_failure_is_reported_not_hidden(built, monkeypatch):
+    """an exchange that fails mid-schedule (a dead peer, an RCCL error) must surface as the reference's only failure
+    convention, t[ALL] = 99999999 (offt-compute.c:3881), plus offt_hip_last_error() -- never as a normal return"""
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    monkeypatch.setenv("OFFT_FORCE_A2A", "1")
+    for kw in (dict(T1=2, W1=1, T2=2), dict(T1=2, W1=1, S=1)):
+        cpu_world.install(0, 1, fail_after=3)
+        try:
+            with pytest.raises(RuntimeError, match="offt_3d_execute"):
+                cpu_world.run_rank(8, 8, 8, **kw)
+        finally:
+            cpu_world.uninstall()
+    # the C-level view of the same failure: the marker in t[ALL]
+    cpu_world.install(0, 1, fail_after=2)
+    try:
+        po = api.offt_3d_init(8, 8, 8, custom_params=api.make_params(T1=2, W1=1))
+        buf = np.zeros(api.local_elems(po), dtype=np.complex128)
+        ptr = buf.ctypes.data_as(C.c_void_p)
+        api.lib().offt_3d_execute(po, ptr, ptr, 0)
+        assert po.contents.t[api.ALL] >= 99999999.0
+        api.offt_3d_fin(po)
+    finally:
+        cpu_world.uninstall()
 
 
 def test_baseline_config0_128cube_two_ranks(built, tmp_path):
