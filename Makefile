@@ -16,7 +16,7 @@ $(BUILD):
 	mkdir -p $(BUILD)
 
 # the kernel instantiations are grouped into several translation units so that `make -j` compiles them in parallel
-HIPSRC    := offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f64_1024 offt_reg_pow2_f64_anysplit offt_reg_pow2_f32 offt_reg_mixed_f64_a offt_reg_mixed_f64_b \
+HIPSRC    := offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f64_1024 offt_reg_pow2_f64_anysplit offt_reg_pow2_f32 offt_reg_pow2_f32_anysplit offt_reg_mixed_f64_a offt_reg_mixed_f64_b \
              offt_reg_mixed_f64_c offt_reg_mixed_f64_d offt_reg_mixed_f64_e offt_reg_mixed_f32_a offt_reg_mixed_f32_b
 HIPOBJ    := $(HIPSRC:%=$(BUILD)/%.o)
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/offt_panel.hpp $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h $(CSRC)/offt_wr_consts.h | $(BUILD)
@@ -57,13 +57,14 @@ tests/libcpubackend.so: tests/cpu_backend.c oracle/oracle_fft.c oracle/oracle.h 
 	$(CC) -std=gnu11 -O2 -fPIC -shared -Ioracle -Ioffamd -I$(CSRC) -o $@ tests/cpu_backend.c oracle/oracle_fft.c -lm
 
 # run-fft-compatible C harness.  MPI=1 builds the multi-rank variant
-# against an MPI found at MPI_PREFIX (e.g. /opt/conda).
+# against an MPI found at MPI_PREFIX (e.g. /opt/conda; linked by file name, not -L: a conda lib directory also holds an
+# older libstdc++ that must not shadow the system one the HIP runtime needs).
 MPI_PREFIX ?= /opt/conda
 harness: bin/run-fft
 bin/run-fft: harness/run-fft.c offt_amd/liboffthip.so
 	mkdir -p bin
 ifeq ($(MPI),1)
-	$(CC) -std=gnu11 -O2 -Wall -DOFFT_HARNESS_MPI -Iinclude -I$(MPI_PREFIX)/include -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -L$(MPI_PREFIX)/lib -lmpi -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath,$(MPI_PREFIX)/lib
+	$(CC) -std=gnu11 -O2 -Wall -DOFFT_HARNESS_MPI -Iinclude -I$(MPI_PREFIX)/include -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 $(MPI_PREFIX)/lib/libmpi.so -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath,$(MPI_PREFIX)/lib
 else
 	$(CC) -std=gnu11 -O2 -Wall -Iinclude -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib
 endif

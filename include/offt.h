@@ -1,6 +1,12 @@
 /*
  * offt.h -- plan / execute API of the MI355X-native 3-D parallel FFT.
  *
+ * The declarations below reproduce the public interface (struct layouts, field names, macro names, prototypes) of
+ * offt.h from OFFT, University of Maryland's auto-tuned parallel FFT algorithm (rchyena/offt),
+ * Copyright 2016 Jeffrey K. Hollingsworth, distributed under the GNU Lesser General Public License, version 3 or
+ * (at your option) any later version <http://www.gnu.org/licenses/>.  Only that interface is reproduced, so that code
+ * written against the original header compiles against this one; the implementation behind it is independent.
+ *
  * Drop-in boundary: this header declares exactly the public surface of the
  * reference's offt.h (rchyena/offt, offt.h:69-259, built with its Hopper flags
  * -DA2AV -DSTRIDE and the in-header NOTEST switch), so that a caller such as

@@ -400,7 +400,7 @@ typedef struct hip_state {
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
-  int wpad;
+  int wpad, wrow;      /* scratch volume W: extra elements per x-plane / per y-line (de-aliasing pads) */
   int async;
   int timed;            /* this call records timing events (synchronous call, or host-staged) */
   double last_dev_s, pass_s[3];
@@ -707,6 +707,9 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   /* scratch planes are offset by an odd number of 128-B lines so that the 8 x-planes a
    * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt) */
   st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : 72;
+  /* ... and its y-lines can be given a pad too, so that the z pass's strided stores (one 128-B segment per line, lines
+   * Ny elements apart) do not all fall on the same HBM channels when Ny * 16 B is a large power of two */
+  st->wrow = getenv("OFFT_WROWPAD") ? atoi(getenv("OFFT_WROWPAD")) : 0;
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
   if (!g_backend) {
@@ -742,7 +745,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
 
   if (!st->use_pipeline) {
     if (!po->params->v[_S_]) { /* transposed output layouts need one scratch volume */
-      st->work_elems = (size_t)Nx * ((size_t)Ny * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
+      st->work_elems = (size_t)Nx * ((size_t)(Ny + st->wrow) * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
     }
@@ -1121,7 +1124,8 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
      *   P3  out[z][y][x] --FFTx--> in place
      * this replaces FFTz + pack/unpack + setup_transpose's xzy->zxy permutation
      * + FFTy + FFTx of the reference (offt-compute.c:625-634, 4019-4036). */
-    const long long wx = (long long)Nz * Ny + st->wpad; /* W plane (+ optional pad, elements) */
+    const long long wy = Ny + st->wrow;                 /* W line pitch */
+    const long long wx = (long long)Nz * wy + st->wpad; /* W plane (+ optional pad, elements) */
     desc_init(&d[0], st, Nzf, dir, 2);
     d[0].real_input = po->is_r2c;
     desc_init(&d[1], st, Ny, dir, 1);
@@ -1129,9 +1133,9 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
     if (dir < 0) {
       d[0].ncols = Ny; d[0].nb1 = Nx;
       d[0].in_axis_stride = 1; d[0].in_col_stride = is1; d[0].in_b1_stride = is0; d[0].in_contig = 1;
-      d[0].out_axis_stride = Ny; d[0].out_col_stride = 1; d[0].out_b1_stride = wx; d[0].out_contig = 0;
+      d[0].out_axis_stride = wy; d[0].out_col_stride = 1; d[0].out_b1_stride = wx; d[0].out_contig = 0;
       d[1].ncols = Nx; d[1].nb1 = Nz;
-      d[1].in_axis_stride = 1; d[1].in_col_stride = wx; d[1].in_b1_stride = Ny; d[1].in_contig = 1;
+      d[1].in_axis_stride = 1; d[1].in_col_stride = wx; d[1].in_b1_stride = wy; d[1].in_contig = 1;
       d[1].out_axis_stride = os1; d[1].out_col_stride = os0; d[1].out_b1_stride = os2; d[1].out_contig = 0;
       d[2].ncols = Ny; d[2].nb1 = Nz;
       d[2].in_axis_stride = d[2].out_axis_stride = os0;
@@ -1150,9 +1154,9 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
       d[2].in_contig = d[2].out_contig = 1;
       d[1].ncols = Nx; d[1].nb1 = Nz;
       d[1].in_axis_stride = os1; d[1].in_col_stride = os0; d[1].in_b1_stride = os2; d[1].in_contig = 0;
-      d[1].out_axis_stride = 1; d[1].out_col_stride = wx; d[1].out_b1_stride = Ny; d[1].out_contig = 1;
+      d[1].out_axis_stride = 1; d[1].out_col_stride = wx; d[1].out_b1_stride = wy; d[1].out_contig = 1;
       d[0].ncols = Ny; d[0].nb1 = Nx;
-      d[0].in_axis_stride = Ny; d[0].in_col_stride = 1; d[0].in_b1_stride = wx; d[0].in_contig = 0;
+      d[0].in_axis_stride = wy; d[0].in_col_stride = 1; d[0].in_b1_stride = wx; d[0].in_contig = 0;
       d[0].out_axis_stride = 1; d[0].out_col_stride = is1; d[0].out_b1_stride = is0; d[0].out_contig = 1;
       t = d[0]; d[0] = d[2]; d[2] = t; /* launch order x, y, z */
       src[0] = data; dst[0] = data; src[1] = data; dst[1] = W; src[2] = W; dst[2] = data;

@@ -341,6 +341,7 @@ void build_registry() {
   reg_pow2_f64_1024();
   reg_pow2_f64_anysplit();
   reg_pow2_f32();
+  reg_pow2_f32_anysplit();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
   reg_mixed_f64_c();
@@ -733,6 +734,14 @@ int offt_hipk_prepare(int n, int precision) {
   if (get_tables(n, precision, tb, true)) return -1;
   // a 13-smooth length of 256 .. 4096 points without a precompiled panel kernel gets one now (best effort)
   if (rtc_enabled() && n >= 256 && n <= 4096 && smooth13(n) && !find_variant(n, precision, true, true, -1)) (void)rtc_build(n, precision);
+  // a length neither a panel kernel nor the any-length kernel (two ping-pong images of one line in LDS) can take is
+  // refused HERE, at plan time: offt_3d_init returns NULL instead of every execute failing
+  const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  if (!find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024) {
+    snprintf(g_err, sizeof g_err, "no kernel for lines of %d %s points: no register kernel, and the any-length kernel holds at most %zu",
+             n, precision == OFFT_PREC_F64 ? "double-complex" : "single-complex", (size_t)160 * 1024 / (2 * esz));
+    return -1;
+  }
   return 0;
 }
 
@@ -768,7 +777,9 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
     xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
-    void *args[] = {(void *)&a, (void *)&in, (void *)&out, v->full_table ? (void *)&tb.full : (void *)&tb.quarter};
+    // every panel kernel stages its twiddles from the exact full-wave table w^m, m < n (the quarter- and half-wave
+    // tables they keep in LDS are prefixes of it)
+    void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tb.full};
     if (v->modfn) {  // plan-time instance: a module function
       HIPK_CHECK(hipModuleLaunchKernel((hipFunction_t)v->modfn, (unsigned)nblk, 1, 1, v->threads, 1, 1, (unsigned)v->lds, st, args, nullptr));
       return 0;

@@ -71,6 +71,11 @@ __device__ __forceinline__ void gstore(V2 *p, V2 v) {
 #endif
 }
 
+// v with its sign bit XORed by m (m = 0 or 0x80000000, uniform): conjugation and half-wave twiddle signs cost one
+// 32-bit XOR instead of a select + negate
+__device__ __forceinline__ double xor_sign(double v, unsigned m) { return __hiloint2double(__double2hiint(v) ^ (int)m, __double2loint(v)); }
+__device__ __forceinline__ float xor_sign(float v, unsigned m) { return __int_as_float(__float_as_int(v) ^ (int)m); }
+
 // i / d for 0 <= i < 2^22 with inv = 1.0f / d: float estimate, one correction step each way
 __device__ __forceinline__ int fdiv(int i, int d, float inv) {
   int q = (int)((float)i * inv);
@@ -200,16 +205,36 @@ struct PanelCfg {
   // column pitch == 4 (mod 32) elements: the 8 columns x 4 rows of one 32-lane ds_read_b64
   // group of a strided-store flavour land in 32 distinct bank pairs
   static constexpr int LSTRIDE = SWZ ? ((NPAD + 31) / 32) * 32 + 4 : ((NPAD + 13) / 16) * 16 + 2;
-  static constexpr int QT = (N >= 4) ? N / 4 + 1 : 1;
   static constexpr size_t EX_BYTES =
       NSTAGE > 1 ? (size_t)COLS * LSTRIDE * sizeof(T) * (SPLIT ? 1 : 2) : 0;
   static constexpr size_t TW_OFF = (EX_BYTES + 15) / 16 * 16;
-  static constexpr size_t LDS_BYTES = NSTAGE > 1 ? TW_OFF + (size_t)QT * 2 * sizeof(T) : 0;
+  // Inter-stage twiddles, staged in LDS from the exact full-wave table in global memory:
+  //  * one table for all stages: the QUARTER wave (N/4+1 entries; the other three quadrants by swap / sign, ~10 integer
+  //    instructions per twiddle) or the HALF wave (N/2 entries; w^(e + N/2) = -w^e is one XOR) -- the half wave whenever it
+  //    does not cost a workgroup per CU;
+  //  * a COMPACT table for stage 1, tw1[t-1][k] = w^(k t N/(R0 R1)), k < R0, t < R1: the 16 lanes of an LDS read group
+  //    then read 16 consecutive entries instead of entries 16 t N/(R0 R1) bytes apart (the r02 PMC pass showed
+  //    SQ_LDS_BANK_CONFLICT = 55-60 % of SQ_LDS_IDX_ACTIVE on the 2048-point kernels, from exactly these reads) -- again
+  //    only when it does not cost a workgroup per CU.
+  static constexpr int QTQ = (N >= 4) ? N / 4 + 1 : 1, QTH = N / 2, T1N = NSTAGE > 1 ? R0 * (R1 - 1) : 0;
+  static constexpr size_t lds_with(int shared_entries, int t1_entries) {
+    return NSTAGE > 1 ? TW_OFF + ((size_t)shared_entries + (size_t)t1_entries) * 2 * sizeof(T) : 0;
+  }
+  static constexpr int wg_for(size_t lds) { return lds ? (int)(160 * 1024 / lds) : 8; }
+#ifdef OFFT_NO_OPT_TW
+  static constexpr bool USE_T1 = false, USE_HALF = false;
+#else
+  static constexpr bool USE_T1 = NSTAGE > 1 && wg_for(lds_with(QTQ, T1N)) == wg_for(lds_with(QTQ, 0));
+  static constexpr bool USE_HALF = NSTAGE > 1 && N >= 16 && wg_for(lds_with(QTH, USE_T1 ? T1N : 0)) == wg_for(lds_with(QTQ, 0));
+#endif
+  static constexpr int QT = USE_HALF ? QTH : QTQ;
+  static constexpr size_t T1_OFF = TW_OFF + (size_t)QT * 2 * sizeof(T);
+  static constexpr size_t LDS_BYTES = lds_with(QT, USE_T1 ? T1N : 0);
   // occupancy target handed to __launch_bounds__ (2nd argument = waves per
   // SIMD): as many workgroups per CU as the 160 KiB LDS admits, at most 4
   // waves per SIMD -- enough to overlap one group's butterflies with another
   // group's HBM traffic without starving the register allocator.
-  static constexpr int WG_PER_CU_LDS = LDS_BYTES ? (int)(160 * 1024 / LDS_BYTES) : 8;
+  static constexpr int WG_PER_CU_LDS = wg_for(LDS_BYTES);
   static constexpr int WPS_RAW = (WG_PER_CU_LDS * NT + 255) / 256;
   static constexpr int WPS = WPS_RAW < 1 ? 1 : (WPS_RAW > 4 ? 4 : WPS_RAW);
   // register budget: an E-point thread keeps E*sizeof(T)/2 data VGPRs; it needs
@@ -244,10 +269,19 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   T *exs = reinterpret_cast<T *>(smem);
   V2 *exv = reinterpret_cast<V2 *>(smem);
   V2 *tw = reinterpret_cast<V2 *>(smem + Cfg::TW_OFF);
+  V2 *tw1 = reinterpret_cast<V2 *>(smem + Cfg::T1_OFF);
 
   const int tid = threadIdx.x;
   if constexpr (NSTAGE > 1) {
+    // twq = the exact full-wave table w^m, m < N, in global memory (L2-resident: every workgroup reads it)
     for (int i = tid; i < Cfg::QT; i += NT) tw[i] = twq[i];
+    if constexpr (Cfg::USE_T1) {
+      constexpr int M1 = N / (R0 * R1);
+      for (int i = tid; i < Cfg::T1N; i += NT) {
+        const int t = i / R0 + 1, k = i - (t - 1) * R0;
+        tw1[i] = twq[k * M1 * t];  // k t M1 <= (R0-1)(R1-1) M1 < N
+      }
+    }
   }
 
   // panel -> (column panel, b1, b2)
@@ -257,10 +291,19 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   const int b1 = rest % (unsigned)a.nb1;
   const int b2 = rest / (unsigned)a.nb1;
   const int c0 = cp * COLS;
+#ifdef OFFT_NO_OPT_CONJ
+  const unsigned conj_mask = 0u;
+#else
+  const unsigned conj_mask = a.conj ? 0x80000000u : 0u;  // inverse transform = conj-in / conj-out: one XOR per element
+#endif
 
   cx<T> v[E];
 
   // ---------------- stage 0: global load -------------------------------------
+  // Element (u, t) of this thread is axis index n = j + cn with cn = u TPL + t N/R0, a compile-time multiple of TPL.
+  // Unless a per-peer split is SHORTER than TPL, j and cn never carry into each other's block / offset bits, so the
+  // address is (a per-lane base for j) + (a wave-uniform offset for cn): the offsets are scalar-unit work and an element
+  // costs a 64-bit add instead of two 64-bit multiply-adds (the ISA of the r01 kernels had 130 v_mad_u64_u32 per thread).
   int c, j;
   if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
   else               { c = tid % COLS; j = tid / COLS; }
@@ -268,20 +311,40 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     const bool valid = (c0 + c) < a.ncols;
     const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
     const int mask = (int)((1u << a.in_shift) - 1u);
-    static_for<0, E>([&](auto ii) {
-      constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
-      const int n = j + u * TPL + t * (N / R0);
-      V2 val;
-      val.x = 0; val.y = 0;
-      if constexpr (R2C) {
-        // n real values at the head of the row: element n is the n-th T of the row
-        if (valid) val.x = reinterpret_cast<const T *>(src)[n];
-        v[decltype(ii)::value] = cx<T>{val.x, (T)0};
-      } else {
-        if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
-        v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
-      }
-    });
+    auto load_all = [&](auto fast) {
+      constexpr bool FAST = decltype(fast)::value;
+      const V2 *p0 = src + (FAST ? (long long)j * a.in_axis : 0LL);
+      static_for<0, E>([&](auto ii) {
+        constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
+        constexpr int cn = u * TPL + t * (N / R0);
+        const int n = j + cn;
+        V2 val;
+        val.x = 0; val.y = 0;
+        if constexpr (R2C) {
+          // n real values at the head of the row: element n is the n-th T of the row
+          if (valid) val.x = reinterpret_cast<const T *>(src)[n];
+          v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+        } else {
+          if constexpr (FAST) {
+            const long long off = (long long)(cn >> a.in_shift) * a.in_blk + (long long)(cn & mask) * a.in_axis;  // uniform
+            if (valid) val = gload(p0 + off);
+          } else {
+            if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
+          }
+#ifdef OFFT_NO_OPT_CONJ
+          v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
+#else
+          v[decltype(ii)::value] = cx<T>{val.x, xor_sign(val.y, conj_mask)};
+#endif
+        }
+      });
+    };
+#ifdef OFFT_NO_OPT_ADDR
+    load_all(std::false_type{});
+#else
+    if ((1u << a.in_shift) >= (unsigned)TPL) load_all(std::true_type{});
+    else load_all(std::false_type{});
+#endif
   }
 
   // ---------------- stages ---------------------------------------------------
@@ -301,15 +364,26 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         const int km = (q & (Ns - 1)) * M;
         static_for<1, R>([&](auto tt) {
           constexpr int t = decltype(tt)::value;
-          const int e = km * t;
-          const int qd = e / (N / 4);
-          const int r = e & (N / 4 - 1);
-          V2 w = tw[r];
-          T wr = w.x, wi = w.y;
-          // multiply by (-i)^qd
-          T cr = (qd & 1) ? wi : wr;
-          T ci = (qd & 1) ? -wr : wi;
-          if (qd & 2) { cr = -cr; ci = -ci; }
+          T cr, ci;
+          if constexpr (s == 1 && Cfg::USE_T1) {
+            const V2 w = tw1[(t - 1) * R0 + (q & (R0 - 1))];  // consecutive lanes, consecutive entries
+            cr = w.x; ci = w.y;
+          } else if constexpr (Cfg::USE_HALF) {
+            const int e = km * t;                              // < N
+            const V2 w = tw[e & (N / 2 - 1)];
+            const unsigned sm = ((unsigned)e << (32 - ilog2(N))) & 0x80000000u;  // bit log2(N)-1 of e: w^(e) = -w^(e - N/2)
+            cr = xor_sign(w.x, sm); ci = xor_sign(w.y, sm);
+          } else {
+            const int e = km * t;
+            const int qd = e / (N / 4);
+            const int r = e & (N / 4 - 1);
+            V2 w = tw[r];
+            T wr = w.x, wi = w.y;
+            // multiply by (-i)^qd
+            cr = (qd & 1) ? wi : wr;
+            ci = (qd & 1) ? -wr : wi;
+            if (qd & 2) { cr = -cr; ci = -ci; }
+          }
           cx<T> x = v[u * R + t];
           v[u * R + t] = cx<T>{x.x * cr - x.y * ci, x.x * ci + x.y * cr};
         });
@@ -380,16 +454,42 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
       const int mask = (int)((1u << a.out_shift) - 1u);
       const T sc = (T)a.scale;
-      static_for<0, E>([&](auto ii) {
-        constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
-        const int n = j + u * TPL + t * (N / R);
-        cx<T> x = v[u * R + bitrev(t, LR)];
-        V2 w;
-        w.x = x.x * sc;
-        w.y = (a.conj ? -x.y : x.y) * sc;
-        if (valid && (!R2C || n <= N / 2))
-          gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
-      });
+#ifdef OFFT_NO_OPT_CONJ
+      const T scy = sc;
+#else
+      const T scy = a.conj ? -sc : sc;  // conj-out rides on the scale
+#endif
+      auto store_all = [&](auto fast) {
+        constexpr bool FAST = decltype(fast)::value;
+        V2 *p0 = dst + (FAST ? (long long)j * a.out_axis : 0LL);
+        static_for<0, E>([&](auto ii) {
+          constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
+          constexpr int cn = u * TPL + t * (N / R);
+          const int n = j + cn;
+          cx<T> x = v[u * R + bitrev(t, LR)];
+          V2 w;
+          w.x = x.x * sc;
+#ifdef OFFT_NO_OPT_CONJ
+          w.y = (a.conj ? -x.y : x.y) * sc;
+#else
+          w.y = x.y * scy;
+#endif
+          if (valid && (!R2C || n <= N / 2)) {
+            if constexpr (FAST) {
+              const long long off = (long long)(cn >> a.out_shift) * a.out_blk + (long long)(cn & mask) * a.out_axis;  // uniform
+              gstore(p0 + off, w);
+            } else {
+              gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
+            }
+          }
+        });
+      };
+#ifdef OFFT_NO_OPT_ADDR
+      store_all(std::false_type{});
+#else
+      if ((1u << a.out_shift) >= (unsigned)TPL) store_all(std::true_type{});
+      else store_all(std::false_type{});
+#endif
     }
   });
 }
@@ -814,6 +914,7 @@ void reg_pow2_f64();
 void reg_pow2_f64_1024();
 void reg_pow2_f64_anysplit();
 void reg_pow2_f32();
+void reg_pow2_f32_anysplit();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();
 void reg_mixed_f64_c();

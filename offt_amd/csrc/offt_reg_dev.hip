@@ -8,6 +8,17 @@ void reg_dev() {
   reg_variant<double, 1024, 32, 32, 32, 1, 8, true>(0, 0);
   reg_variant<double, 1024, 16, 16, 16, 4, 8, true>(1, F_ALL);
 #endif
+#ifdef OFFT_DEV_R2  /* round 2: the product defaults of the 2048-point kernels (+ 256 for 2048 x 256 x 2048 slabs) */
+  reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0);
+  reg_variant<double, 2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<double, 2048, 32, 32, 32, 2, 4, true>(1, F_CC);
+  reg_variant<double, 2048, 16, 16, 16, 8, 4, true>(2, 0);
+  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(0, F_SS);
+  reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
+  reg_variant<float, 2048, 32, 16, 16, 8, 16, true>(3, 0);
+#endif
 #ifdef OFFT_DEV_512
   reg_variant<double, 512, 16, 16, 16, 2, 8, true>(0, F_ALL);
   reg_variant<double, 512, 16, 16, 8, 4, 8, true>(1, 0);

@@ -1,0 +1,55 @@
+"""bench.py as its own multi-rank launcher (no GPU here): `python bench.py --gpus N` without WORLD_SIZE spawns N rank
+processes, watches them and relays rank 0's line -- one command, like the reference's `mpiexec ... ./run-fft`
+(job-test.sh:9-13, run-fft.c:158-160).  --launch-selftest replaces the GPU work by a gloo rendezvous."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args, env=None, timeout=180):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode(), time.time() - t0
+
+
+def test_two_ranks_are_spawned_and_rank0_line_is_relayed():
+    rc, out, err, _ = run(["--gpus", "2", "--launch-selftest"])
+    assert rc == 0, err
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["selftest"] and line["n_gpus"] == 2 and line["n_ranks_seen"] == 2
+    assert line["master"].startswith("127.0.0.1:")
+
+
+def test_single_rank_needs_no_launcher():
+    rc, out, err, _ = run(["--gpus", "1", "--launch-selftest"])
+    assert rc == 0, err
+    assert json.loads(out.strip().splitlines()[-1])["n_ranks_seen"] == 1
+
+
+def test_failing_rank_fails_the_run_with_its_tail():
+    rc, out, err, dt = run(["--gpus", "2", "--launch-selftest"], env={"OFFT_BENCH_SELFTEST_FAIL_RANK": "1"})
+    assert rc != 0
+    assert "rank 1 exited with code 3" in err and "fails on purpose" in err
+    assert out.strip() == ""      # no half result
+    assert dt < 120               # the surviving rank was stopped, nobody waited for a rendezvous time-out
+
+
+def test_hung_rank_hits_the_wall_clock_limit():
+    rc, out, err, dt = run(["--gpus", "2", "--launch-selftest", "--launch-timeout", "6"], env={"OFFT_BENCH_SELFTEST_HANG_RANK": "0"})
+    assert rc != 0
+    assert "wall-clock limit" in err
+    assert dt < 60
+
+
+def test_under_an_external_launcher_no_ranks_are_spawned():
+    """WORLD_SIZE set (torch.distributed.run): the process is a rank, not a launcher"""
+    rc, out, err, _ = run(["--gpus", "1", "--launch-selftest"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                                                                         MASTER_PORT="29631"))
+    assert rc == 0, err
+    assert json.loads(out.strip().splitlines()[-1])["n_ranks_seen"] == 1

@@ -70,3 +70,34 @@ def test_fails_loudly_without_gpu(built):
         assert "no HIP device" in str(e) or "hip" in str(e).lower()
     else:
         raise AssertionError("offt_3d_init succeeded without a GPU")
+
+
+def test_product_library_has_no_test_seams(built):
+    """the test-only entry points of offt_backend.h exist in tests/liboffthip_test.so only"""
+    import subprocess
+    syms = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    assert "offt_hip_test_" not in syms
+    tsyms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tests", "liboffthip_test.so")]).decode()
+    assert "offt_hip_test_set_backend" in tsyms and "offt_hip_test_set_transport" in tsyms
+
+
+def test_mpi_harness_compiles_and_links(built, tmp_path):
+    """`make harness MPI=1` (rank/size from MPI, RCCL id by MPI_Bcast -- the reference's launch model,
+    run-fft.c:158-160): compile and link against the image's MPICH; it cannot run without GPUs"""
+    import shutil
+    import subprocess
+    import pytest
+    if not os.path.exists("/opt/conda/include/mpi.h"):
+        pytest.skip("no MPI in this image")
+    exe = tmp_path / "run-fft-mpi"
+    cmd = ["gcc", "-std=gnu11", "-O2", "-Wall", "-DOFFT_HARNESS_MPI", "-I" + os.path.join(ROOT, "include"), "-I/opt/conda/include",
+           "-o", str(exe), os.path.join(ROOT, "harness", "run-fft.c"), "-L" + os.path.join(ROOT, "offt_amd"), "-loffthip",
+           "-L/opt/rocm/lib", "-lamdhip64", "/opt/conda/lib/libmpi.so", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "offt_amd"),
+           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/conda/lib"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", str(exe)]).decode()
+    assert "MPI_Bcast" in syms and "offt_hip_set_world" in syms and "offt_3d_execute" in syms
+    # without -d the harness must leave the mesh to the library (run-fft.c:290-293 only sizes the buffer with p1 = p)
+    src = open(os.path.join(ROOT, "harness", "run-fft.c")).read()
+    assert "p1 = cp->v[_P1_] = p;" not in src

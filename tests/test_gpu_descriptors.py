@@ -175,5 +175,7 @@ def test_split_routing(libs):
     assert name(768, out_split=96) == "fft_panelx_k"
     assert name(1000, in_split=142, in_nfloor=1) == "fft_panelx_k"        # 1000 over 7 peers
     assert name(127) == "fft_mixed_k"
-    assert name(1024, out_split=341, out_nfloor=2, prec=api.F32) == "fft_mixed_k"  # no f32 any-split instances
+    assert name(1024, out_split=341, out_nfloor=2, prec=api.F32) == "fft_panelx_k"  # f32 any-split instances (round 2)
+    assert name(2048, in_split=292, in_nfloor=3, prec=api.F32) == "fft_panelx_k"    # 2048 over 7 peers, single precision
+    assert name(127, prec=api.F32) == "fft_mixed_k"
 

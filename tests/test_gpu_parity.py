@@ -239,6 +239,85 @@ def test_single_precision(built, n):
         assert rel(got.astype(np.complex128), want) <= TOL32
 
 
+@pytest.mark.parametrize("shape", [(2048, 8, 8), (8, 2048, 8), (8, 8, 2048)])
+def test_single_precision_2048_sides(built, shape):
+    """BASELINE configs[4] kernels: a 2048-point single-precision pass on every axis, every output layout, against
+    the oracle (double) with the single-precision tolerance"""
+    for layout in (dict(S=1), dict(), dict(is_equalxy=1)):
+        if layout.get("is_equalxy") and shape[0] != shape[1]:
+            continue
+        got, _ = gpu_fft(shape, precision=api.F32, **layout)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **{("is_equalxy" if k == "is_equalxy" else k): v for k, v in layout.items()})
+        assert rel(got.astype(np.complex128), want) <= TOL32, (shape, layout)
+    # forced tile pipeline (the multi-rank kernels' addressing) in single precision
+    os.environ["OFFT_FORCE_PIPELINE"] = "1"
+    try:
+        got, _ = gpu_fft(shape, precision=api.F32, T1=4, T2=4)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, T1=4, T2=4)
+        assert rel(got.astype(np.complex128), want) <= TOL32, shape
+    finally:
+        del os.environ["OFFT_FORCE_PIPELINE"]
+
+
+def test_full_size_2048_single_precision_properties(built):
+    """2048^3 single-complex on one GPU (64 GiB grid + 64 GiB scratch; BASELINE configs[4]'s grid): closed-form ramp
+    spots and Parseval, computed in place with chunked reductions (no full clones)"""
+    n = 2048
+    po = api.offt_3d_init(n, n, n, precision=api.F32)
+    L = api.lib()
+    c = api.comm_dict(po)
+    dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def energy():  # sum of squares in float64, 2^28 floats at a time
+        tot = 0.0
+        step = 1 << 28
+        for i in range(0, dev.numel(), step):
+            tot += float(dev[i:i + step].double().square().sum())
+        return tot
+
+    # ramp scaled to keep single precision honest: re = (z + 10 y + 100 x) / 2^18, so that X[0,0,0] ~ 2^33 * 0.43
+    L.offt_hip_fill_input(po, dev.data_ptr(), 0)
+    torch.cuda.synchronize()
+    L.offt_hip_set_output_scale(po, 2.0 ** -33)
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    cv = torch.view_as_complex(dev.view(-1, 2))
+    os0, os1, os2 = c["ostride"]
+    x000 = n ** 3 * 111 * (n - 1) / 2 * 2.0 ** -33
+    assert abs(complex(cv[0]) - x000) / x000 < 2e-6
+    cf1 = abs(n ** 3 * (-0.5 + 0.5j / np.tan(np.pi / n)) * 2.0 ** -33)
+    for k in (1, 2, 3, 1023):
+        cf = n ** 3 * (-0.5 + 0.5j / np.tan(np.pi * k / n)) * 2.0 ** -33
+        # single precision: errors scale with the large low-frequency bins of the ramp, not with the bin itself
+        # (|X[0,0,1023]| is 650 times smaller than |X[0,0,1]|): relative to the bin for k <= 3, to |X[0,0,1]| beyond
+        ref = abs(cf) if k <= 3 else cf1
+        assert abs(complex(cv[k * os2]) - cf) / ref < 5e-6
+        assert abs(complex(cv[k * os1]) - 10 * cf) / (10 * ref) < 5e-6
+        assert abs(complex(cv[k * os0]) - 100 * cf) / (100 * ref) < 5e-6
+    assert abs(complex(cv[os0 + os1 + os2])) / abs(x000) < 1e-6
+    # Parseval on the seeded hash field: sum |X|^2 = E * sum |x|^2 (unnormalised forward transform)
+    torch.cuda.synchronize()
+    L.offt_hip_fill_input(po, dev.data_ptr(), 1)
+    torch.cuda.synchronize()
+    e_in = energy()
+    L.offt_hip_set_output_scale(po, 2.0 ** -16)   # exact power of two: |X|^2 scaled by 2^-32 = 1 / sqrt(E)^... see below
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    e_out = energy()
+    api.offt_3d_fin(po)
+    # E = 2^33, scale^2 = 2^-32: e_out = 2^-32 * 2^33 * e_in = 2 e_in
+    assert abs(e_out / (2.0 * e_in) - 1.0) < 1e-5
+
+
+def test_lengths_no_kernel_takes_are_refused_at_plan_time(built):
+    """a line too long for every kernel (no register kernel, more than the any-length kernel's LDS) must fail in
+    offt_3d_init, not on every execute (the reference's FFTW takes any N; this library says so up front)"""
+    for shape, prec in (((8, 8, 6000), api.F64), ((8192, 4, 4), api.F64), ((4, 12000, 4), api.F32)):
+        with pytest.raises(RuntimeError, match="offt_3d_init failed"):
+            api.offt_3d_init(*shape, precision=prec)
+    po = api.offt_3d_init(8, 8, 5000)   # 5000 = 2^3 5^4 fits the any-length kernel
+    api.offt_3d_fin(po)
+
+
 def test_linearity_and_shift(built):
     n = 64
     f, g = O.hash_field(n, n, n), O.hash_field(n, n, n, 7, 11, 13)
@@ -369,3 +448,7 @@ def test_harness_and_static_sweep(built, tmp_path):
     out2 = subprocess.check_output([exe, "-N", str(n), "-n", str(n), "-L", str(n), "-l", "4"], env=env,
                                    stderr=subprocess.STDOUT).decode()
     assert len(open(db).read().splitlines()) == len(pts), out2
+    # a run the library cannot do must FAIL: non-zero exit and the reference's t_min 999999999 line, not timings of
+    # an untransformed buffer (8192 points: no kernel takes the line)
+    p = subprocess.run([exe, "-N", "8192", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode != 0 and "t_min 999999999" in p.stdout.decode(), p.stdout.decode()

@@ -49,6 +49,45 @@ def run_world(size, cases, tmp_path):
                 assert np.linalg.norm(back / np.prod(shape) - blk) / np.linalg.norm(blk) < 1e-13, (case, r)
 
 
+def run_thread_world(size, cases, tmp_path):
+    """`size` ranks as threads of ONE process on the one GPU (the box admits at most 6 processes on the card)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_thread_world.py"), str(size), json.dumps(cases), str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    summary = json.load(open(tmp_path / "summary.json"))
+    assert len(summary) == len(cases)
+    for rec in summary:
+        for k in ("rel_numpy", "rel_oracle", "rel_inverse"):
+            if k in rec:
+                assert rec[k] < rec["tol"], rec
+    return summary
+
+
+def test_eight_ranks_one_gpu_bench_meshes(built, tmp_path):
+    """BASELINE configs[3] as far as one GPU can take it: the 8-rank meshes of the multi-GPU bench -- 1x8 (headline),
+    the reference default 2x4, 8x1 -- at 256^3 and on a ragged grid, forward and inverse, r2c"""
+    cases = [dict(N=[256, 256, 256], params=dict(P1=1)), dict(N=[256, 256, 256], params=dict()),
+             dict(N=[256, 256, 256], params=dict(P1=8)), dict(N=[256, 256, 256], params=dict(P1=2), env=dict(OFFT_MIN_MSG=0)),
+             dict(N=[100, 72, 90], params=dict(P1=2, T1=7, T2=5)), dict(N=[100, 72, 90], params=dict(P1=1)),
+             dict(N=[128, 128, 128], params=dict(), inv=1), dict(N=[128, 128, 128], params=dict(P1=1), inv=1),
+             dict(N=[128, 64, 256], params=dict(P1=4), r2c=1), dict(N=[128, 128, 128], params=dict(P1=4, S=1, T2=8))]
+    s = run_thread_world(8, cases, tmp_path)
+    assert s[1]["mesh"] == [2, 4]  # offt-compute.c:3138-3139: the largest divisor of p that is <= sqrt(p)
+
+
+def test_single_precision_worlds_one_gpu(built, tmp_path):
+    """BASELINE configs[4] as far as one GPU can take it: single-precision worlds of 2 and 8 ranks (slab, default
+    pencil mesh, uneven per-peer blocks), tolerance rel-L2 <= 5e-6"""
+    cases2 = [dict(N=[128, 128, 128], params=dict(P1=1), f32=1), dict(N=[128, 128, 128], params=dict(P1=2), f32=1),
+              dict(N=[64, 64, 2048], params=dict(P1=1), f32=1), dict(N=[2048, 32, 32], params=dict(P1=2), f32=1, inv=1)]
+    run_thread_world(2, cases2, tmp_path)
+    cases8 = [dict(N=[256, 256, 256], params=dict(P1=1), f32=1), dict(N=[256, 256, 256], params=dict(), f32=1),
+              dict(N=[64, 2048, 64], params=dict(P1=8), f32=1), dict(N=[128, 128, 128], params=dict(), f32=1, inv=1)]
+    run_thread_world(8, cases8, tmp_path)
+    cases3 = [dict(N=[64, 64, 64], params=dict(P1=1), f32=1), dict(N=[128, 100, 96], params=dict(P1=3), f32=1)]
+    run_thread_world(3, cases3, tmp_path)  # uneven F / F+1 blocks in single precision
+
+
 def test_two_ranks_one_gpu(built, tmp_path):
     cases = [dict(N=[64, 64, 64], params=dict(P1=1)), dict(N=[64, 64, 64], params=dict(P1=2)),
              dict(N=[128, 64, 32], params=dict(P1=1, T1=16, T2=4)), dict(N=[64, 64, 64], params=dict(P1=1, S=1)),
