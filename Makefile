@@ -64,7 +64,7 @@ harness: bin/run-fft
 bin/run-fft: harness/run-fft.c offt_amd/liboffthip.so
 	mkdir -p bin
 ifeq ($(MPI),1)
-	$(CC) -std=gnu11 -O2 -Wall -DOFFT_HARNESS_MPI -Iinclude -I$(MPI_PREFIX)/include -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 $(MPI_PREFIX)/lib/libmpi.so -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath,$(MPI_PREFIX)/lib
+	$(CC) -std=gnu11 -O2 -Wall -DOFFT_HARNESS_MPI -Iinclude -I$(MPI_PREFIX)/include -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 $(MPI_PREFIX)/lib/libmpi.so -lm -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath,$(MPI_PREFIX)/lib
 else
 	$(CC) -std=gnu11 -O2 -Wall -Iinclude -o $@ harness/run-fft.c -Lofft_amd -loffthip -L$(ROCM)/lib -lamdhip64 -lm -Wl,-rpath,'$$ORIGIN/../offt_amd' -Wl,-rpath,$(ROCM)/lib
 endif

@@ -383,6 +383,7 @@ typedef struct hip_state {
   int slab_zyx;          /* p1 == 1 and z-y-x output: single-exchange slab schedule, see execute_slab() */
   int t1_custom, t2_custom; /* the caller fixed T1 / T2 (run-fft -T / -t): use them as given */
   int sT, sTz, sNt, sH;  /* slab schedule: x-tile, z-chunk thickness, #tiles, #chunks */
+  int slab_yc;           /* slab blocks laid out [chunk][x_t][z in chunk][y] (y contiguous), see execute_slab() */
   size_t sblkS;          /* elements per (tile, peer) block of S1 / R1: [z_l][y][x_t] */
   void *S1, *R1, *R2;    /* packed send volume, receive volume (same layout), y-transformed volume */
   void **ev_s1;          /* per x-tile: K1 done */
@@ -418,6 +419,14 @@ static void *hb_malloc(size_t bytes) {
 }
 static void hb_free(void *p) { if (p) (void)hipFree(p); }
 static int hb_pass(const offt_pass_desc *d, const void *in, void *out, void *stream) {
+  /* OFFT_LOG_PASSES=1: one line per launch (kernel family, length, batch, addressing) -- profiling tools match it, in
+   * dispatch order, with the kernel trace of rocprofv3 to turn durations into bytes per second */
+  static int log_passes = -1;
+  if (log_passes < 0) log_passes = getenv("OFFT_LOG_PASSES") && atoi(getenv("OFFT_LOG_PASSES"));
+  if (log_passes && d->n > 0 && d->ncols > 0 && d->nb1 > 0 && d->nb2 > 0)
+    fprintf(stderr, "offt-pass %s n %d ncols %d nb1 %d nb2 %d prec %d in_contig %d out_contig %d in_split %d out_split %d elems %lld\n",
+            offt_hipk_kernel_name(d), d->n, d->ncols, d->nb1, d->nb2, d->precision, d->in_contig, d->out_contig, d->in_split,
+            d->out_split, (long long)d->n * d->ncols * d->nb1 * d->nb2);
   int rc = offt_hipk_fft_pass(d, in, out, stream);
   if (rc) SET_ERR("pass n=%d failed: %s", d->n, offt_hipk_last_error());
   return rc;
@@ -466,7 +475,10 @@ static int hb_a2a(void *ctx, int which, int npeers, const int *peer_rank_in_comm
                   const size_t *sendbytes, void *const *recvp, const size_t *recvbytes, void *stream) {
   hip_state *st = (hip_state *)ctx;
   if (g_test_transport) { /* synchronous, host-staged by the test */
-    HCHECK(hipStreamSynchronize((hipStream_t)stream), return -1);
+    /* (a rehearsal transport that moves nothing may skip the host synchronisation: OFFT_TEST_TRANSPORT_NOSYNC=1) */
+    static int nosync = -1;
+    if (nosync < 0) nosync = getenv("OFFT_TEST_TRANSPORT_NOSYNC") && atoi(getenv("OFFT_TEST_TRANSPORT_NOSYNC"));
+    if (!nosync) HCHECK(hipStreamSynchronize((hipStream_t)stream), return -1);
     return g_test_transport(which, npeers, peer_rank_in_comm, sendp, sendbytes, recvp, recvbytes);
   }
   ncclComm_t cm = which == 1 ? st->comm1 : (which == 2 ? st->comm2 : G.world);
@@ -559,8 +571,13 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
    * per-peer message of exchange 1 is at least 4 MiB (the reference's M1/16 was sized for CPU caches and MPI eager limits) */
   st->T = po->params->v[_T1_];
   if (st->T < 1) st->T = 1;
-  if (!st->t1_custom)
+  if (!st->t1_custom) {
+    /* at most 8 tiles: the reference's M1/16 gives 54-us launches at 1024^3 on 8 ranks (two rounds of workgroups per
+     * launch, 61 % instead of 75 % of the roofline; profiles/r02_rehearse_f64_1024_2x4_first.txt) */
+    const int t8 = (c->M1 + 7) / 8;
+    if (st->T < t8) st->T = t8;
     while (st->T < c->M1 && (size_t)st->T * c->M2 * c->M3 * st->esz < min_msg) st->T *= 2;
+  }
   if (st->T > c->M1) st->T = c->M1;
   st->ntiles = (c->M1 + st->T - 1) / st->T;
   int W = po->params->v[_W1_];
@@ -1299,7 +1316,13 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
 /* second exchange, and the reference's phase 2 (z-tiles of T2 planes:        */
 /* unpack2 + FFTx, offt-compute.c:3682-3862) only needs the planes it works   */
 /* on.  So the exchange is ordered z-chunk-major:                            */
-/*   K1(i)     FFTz of x-tile i, stored per peer as [z_l][y][x_t]   (all i)   */
+/*   K1(i)     FFTz of x-tile i, stored per peer as [z-chunk][x_t][z][y]  (all i) */
+/*             (y contiguous: K1 stores 128-B runs of 8 y at a pitch of one      */
+/*             y-line, K2 then READS whole y-lines -- both passes are the        */
+/*             contig-in / strided-out flavour at kilobyte pitches.  The first   */
+/*             version stored [z_l][y][x_t]: z rows 512 KiB apart at 1024^3 on   */
+/*             8 ranks, 62 % of the roofline instead of 74 %; it remains the     */
+/*             layout for uneven z blocks and ragged chunks)                     */
 /*   a2a(h,i)  z-chunk h of tile i to every peer, chunk-major: chunk 0 tile   */
 /*             by tile behind K1(i), later chunks as one grouped call each    */
 /*   K2(h)     FFTy of chunk h from the receive volume into R2[z_l][y][x]     */
@@ -1345,6 +1368,8 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->sNt = (c->M1 + T - 1) / T;
   st->sH = (c->M3 + Tz - 1) / Tz;
   st->sblkS = (size_t)c->M3 * c->M2 * T;
+  /* y-contiguous block layout (see execute_slab): needs even z blocks that are whole chunks */
+  st->slab_yc = c->b3 == 0 && c->M3 % Tz == 0 && !(getenv("OFFT_SLAB_XC_LAYOUT") && atoi(getenv("OFFT_SLAB_XC_LAYOUT")));
   st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
   st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
   if (!st->S1 || !st->R2) return -1;
@@ -1379,10 +1404,20 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       offt_pass_desc d;
       desc_init(&d, st, po->Nz, -1, 2);
       d.real_input = po->is_r2c;
-      d.ncols = myT; d.nb1 = c->m2;
-      d.in_axis_stride = 1; d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1]; d.in_contig = 1;
-      d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T; d.out_contig = 0;
-      if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
+      d.in_axis_stride = 1; d.in_contig = 1; d.out_contig = 0;
+      if (st->slab_yc) {
+        /* columns = y: block (tile, peer) = [chunk][x_t][z in chunk][y]; z = (peer, chunk, z in chunk) and the peer blocks
+         * are whole numbers of chunk blocks, so one split of length Tz addresses both levels */
+        d.ncols = c->m2; d.nb1 = myT;
+        d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
+        d.out_axis_stride = c->M2; d.out_col_stride = 1; d.out_b1_stride = (long long)Tz * c->M2;
+        d.out_split = Tz; d.out_block_stride = (long long)c->M2 * Tz * T;
+      } else {
+        d.ncols = myT; d.nb1 = c->m2;
+        d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1];
+        d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
+        if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
+      }
       if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, (char *)st->S1 + (size_t)i * p2 * st->sblkS * esz, s, 1)) return -1;
     }
     be->event_record(st->ev_s1[i], s);
@@ -1436,7 +1471,13 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         offt_pass_desc d;
         desc_init(&d, st, po->Ny, -1, 1);
         d.ncols = part == 0 ? T : tail; d.nb1 = nz; d.nb2 = ntile;
-        d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T; d.in_b2_stride = (long long)p2 * blk;
+        d.in_b2_stride = (long long)p2 * blk;
+        if (st->slab_yc) { /* whole y-lines (runs of F2 per peer block), columns = x_t */
+          d.in_axis_stride = 1; d.in_contig = 1;
+          d.in_col_stride = (long long)Tz * c->M2; d.in_b1_stride = c->M2;
+        } else {
+          d.in_axis_stride = T; d.in_col_stride = 1; d.in_b1_stride = (long long)c->M2 * T;
+        }
         if (p2 > 1) { d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0; d.in_block_stride = (long long)blk; }
         d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
         if (run_pass(st, &d, src + (size_t)first * p2 * blk * esz,

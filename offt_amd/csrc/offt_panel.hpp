@@ -300,10 +300,12 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   cx<T> v[E];
 
   // ---------------- stage 0: global load -------------------------------------
-  // Element (u, t) of this thread is axis index n = j + cn with cn = u TPL + t N/R0, a compile-time multiple of TPL.
-  // Unless a per-peer split is SHORTER than TPL, j and cn never carry into each other's block / offset bits, so the
-  // address is (a per-lane base for j) + (a wave-uniform offset for cn): the offsets are scalar-unit work and an element
-  // costs a 64-bit add instead of two 64-bit multiply-adds (the ISA of the r01 kernels had 130 v_mad_u64_u32 per thread).
+  // Element (u, t) of this thread is axis index n = j + cn with j < TPL and cn = u TPL + t N/R0, a compile-time multiple
+  // of TPL.  A per-peer split has a power-of-two length F = 2^shift (any other split runs on fft_panelx_k): for F >= TPL
+  // cn's offset bits plus j stay below F, for F < TPL cn has no offset bits at all -- either way block index and offset
+  // of n are the SUMS of those of j and cn.  So the address is (a per-lane base for j) + (a wave-uniform offset for cn):
+  // the offsets are scalar-unit work and an element costs a 64-bit add instead of two 64-bit multiply-adds (the ISA of the
+  // r01 kernels had 130 v_mad_u64_u32 per thread).
   int c, j;
   if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
   else               { c = tid % COLS; j = tid / COLS; }
@@ -313,7 +315,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     const int mask = (int)((1u << a.in_shift) - 1u);
     auto load_all = [&](auto fast) {
       constexpr bool FAST = decltype(fast)::value;
-      const V2 *p0 = src + (FAST ? (long long)j * a.in_axis : 0LL);
+      const V2 *p0 = src + (FAST ? (long long)(j >> a.in_shift) * a.in_blk + (long long)(j & mask) * a.in_axis : 0LL);
       static_for<0, E>([&](auto ii) {
         constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
         constexpr int cn = u * TPL + t * (N / R0);
@@ -342,8 +344,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 #ifdef OFFT_NO_OPT_ADDR
     load_all(std::false_type{});
 #else
-    if ((1u << a.in_shift) >= (unsigned)TPL) load_all(std::true_type{});
-    else load_all(std::false_type{});
+    load_all(std::true_type{});
 #endif
   }
 
@@ -358,6 +359,11 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     if constexpr (s > 0) {
       // inter-stage twiddles w_N^(k * t * N/(Ns*R)), k = q mod Ns
       constexpr int M = N / (Ns * R);
+#ifndef OFFT_NO_OPT_WAVESYNC
+      // the twiddle tables staged at kernel entry must be visible: exchange 0 had a workgroup barrier unless it was
+      // wave-private
+      if constexpr (s == 1 && (64 % TPL == 0) && (NT % 64 == 0) && INC && !(NSTAGE == 2 && !OUTC)) __syncthreads();
+#endif
       static_for<0, NB>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
         const int q = j + u * TPL;
@@ -409,26 +415,46 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         return cn * LSTRIDE + padidx<SWZ, PS>(jn + u * TPL + t * (N / Rn));
       };
 
-      // (the twiddle table written at kernel entry becomes visible at the first
-      //  barrier below, before any stage-1 lookup)
-      if constexpr (s > 0) __syncthreads();  // previous exchange's reads done
+      // Synchronisation.  With lanes along the line (j = tid % TPL) and TPL a divisor of 64, a wave owns whole columns: it
+      // writes and reads only its own columns' LDS image, DS operations of one wave execute in order, and no workgroup
+      // barrier is needed -- waves drift apart and one wave's butterflies overlap another's LDS traffic.  Only an exchange
+      // whose writer (stage 0 of a strided-in pass) or reader (last stage of a strided-out pass) runs lanes across
+      // columns needs s_barrier.
+#ifdef OFFT_NO_OPT_WAVESYNC
+      constexpr bool PRIV = false, PRIV_W = false;
+#else
+      constexpr bool WAVE_COLS = (64 % TPL == 0) && (NT % 64 == 0);
+      constexpr bool PRIV_W = WAVE_COLS && (s > 0 || INC);                 // writer mapping is wave-private
+      constexpr bool PRIV = PRIV_W && !(next_last && !OUTC);              // ... and so is the reader's
+#endif
+      auto xsync = [&](auto priv) {
+        if constexpr (decltype(priv)::value) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          __syncthreads();
+        }
+      };
+      // previous exchange's reads done (its reader mapping is this exchange's writer mapping)
+      if constexpr (s > 0) xsync(std::integral_constant<bool, PRIV_W>{});
+      constexpr std::integral_constant<bool, PRIV> priv{};
       if constexpr (SPLIT) {
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].x;
         });
-        __syncthreads();
+        xsync(priv);
         T re[E];
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
           re[decltype(ii)::value] = exs[rd_idx(u, t)];
         });
-        __syncthreads();
+        xsync(priv);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           exs[wr_idx(u, t)] = v[u * R + bitrev(t, LR)].y;
         });
-        __syncthreads();
+        xsync(priv);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
           v[decltype(ii)::value] = cx<T>{re[decltype(ii)::value], exs[rd_idx(u, t)]};
@@ -440,7 +466,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
           V2 w; w.x = x.x; w.y = x.y;
           exv[wr_idx(u, t)] = w;
         });
-        __syncthreads();
+        xsync(priv);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
           V2 w = exv[rd_idx(u, t)];
@@ -461,7 +487,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 #endif
       auto store_all = [&](auto fast) {
         constexpr bool FAST = decltype(fast)::value;
-        V2 *p0 = dst + (FAST ? (long long)j * a.out_axis : 0LL);
+        V2 *p0 = dst + (FAST ? (long long)(j >> a.out_shift) * a.out_blk + (long long)(j & mask) * a.out_axis : 0LL);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           constexpr int cn = u * TPL + t * (N / R);
@@ -487,8 +513,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 #ifdef OFFT_NO_OPT_ADDR
       store_all(std::false_type{});
 #else
-      if ((1u << a.out_shift) >= (unsigned)TPL) store_all(std::true_type{});
-      else store_all(std::false_type{});
+      store_all(std::true_type{});
 #endif
     }
   });

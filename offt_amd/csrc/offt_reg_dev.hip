@@ -18,6 +18,7 @@ void reg_dev() {
   reg_variant<float, 2048, 64, 32, 32, 2, 16, true>(1, F_CS | F_SC);
   reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
   reg_variant<float, 2048, 32, 16, 16, 8, 16, true>(3, 0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(4, 0);
 #endif
 #ifdef OFFT_DEV_512
   reg_variant<double, 512, 16, 16, 16, 2, 8, true>(0, F_ALL);

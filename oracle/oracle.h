@@ -5,14 +5,15 @@
  * as the parity checker by tests/, __graft_entry__.smoke() and the cpu_baseline
  * leg of bench.py.  Nothing in offt_amd/ (the product) links, loads or calls it.
  *
- * Pinning status: the reference's arithmetic lives in FFTW3 (not vendored, no
- * version pin beyond Makefile:17-18 "fftw-3.3.2") and the reference has no
- * tests or golden vectors.  The reference is unbuildable in this image without
- * writing a stand-in fftw3.h, so oracle/_ref is not built.  The oracle is
- * pinned instead by (1) outputs of the reference recorded by the survey run
- * (SURVEY.md 8c / BASELINE.md 2: full 18^3 grid on 6 ranks, spot values at
- * 128^3, the default-parameter line for N=128 p=2), committed under
- * tests/golden/, and (2) the DFT definition via numpy.fft (pocketfft).
+ * Pinning status: PARITY UNPINNED.  The reference's arithmetic lives in FFTW3 (not vendored, no
+ * version pin beyond Makefile:17-18 "fftw-3.3.2"), the reference has no tests, golden vectors or
+ * fixtures, and it is unbuildable in this image (it needs fftw3.h / fftw3-mpi.h; writing stand-in
+ * headers is not a reference build), so oracle/_ref is not built.  What the oracle is checked
+ * against -- corroboration, not a pin: (1) numpy.fft (pocketfft) full grids and the closed form of
+ * the harness ramp; (2) outputs the survey stage recorded from a run of the reference that was
+ * linked against declarations-only FFTW headers + MKL (SURVEY.md 8c / BASELINE.md 2: full 18^3 grid
+ * on 6 ranks, spot values at 128^3, the default-parameter line for N=128 p=2), kept under
+ * tests/golden/ and labelled as such.
  */
 #ifndef ORACLE_H
 #define ORACLE_H

@@ -1,6 +1,14 @@
 /*
  * oracle_offt.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
+ * PARITY UNPINNED.  The reference (rchyena/offt) holds no tests, golden vectors or fixtures, and it cannot be built in
+ * this image (offt.h:63-64 includes fftw3.h / fftw3-mpi.h, which are absent; stand-in headers are not a reference
+ * build).  This restatement is therefore checked only against (a) numpy.fft.fftn on seeded fields, (b) the closed form of
+ * the harness ramp, (c) values the survey stage recorded from a run of the reference linked against stand-in FFTW
+ * headers + MKL (tests/golden/ref_n18_*.npz, survey_recorded.json) -- corroboration, NOT a pin.  What IS independently
+ * checked: the FFT values (numpy), and by reading, the decomposition / default-parameter / pack-unpack formulas cited
+ * function by function below.
+ *
  * CPU restatement of the reference's hot path, rchyena/offt offt-compute.c, in
  * its Hopper build (-DA2AV -DSTRIDE, Makefile:27-29): the p ranks of
  * MPI_COMM_WORLD are simulated inside one process and an all-to-all is a set

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Regenerate the committed golden fixtures (run in the development container).
 
-1. ref_n18_p6_p1-2_S1.npz -- OUTPUT OF THE REFERENCE ITSELF: the survey stage
-   compiled the unmodified rchyena/offt sources against MPICH + MKL's FFTW3
-   wrapper symbols and ran `mpiexec -n 6 ./dump 18 2 0 1` (SURVEY.md Appendix D
+PARITY UNPINNED: none of these fixtures is a pin by the reference's own tests (it has none) or by a
+genuine reference build (FFTW is absent from the image).  Item 1 comes from a STAND-IN build and is kept as
+corroboration only; the numerics are pinned by numpy (item 3) and the closed-form ramp.
+
+1. ref_n18_p6_p1-2_S1.npz -- output of a STAND-IN BUILD of the reference: the survey stage
+   compiled the unmodified rchyena/offt sources against declarations-only fftw3.h /
+   fftw3-mpi.h stand-ins, MPICH + MKL's FFTW3 wrapper symbols and ran `mpiexec -n 6 ./dump 18 2 0 1` (SURVEY.md Appendix D
    step 5: N=18, p1=2, is_equalxy=0, S=1, seeded position-hash input).  Each
    rank dumped `gx gy gz re im` through ostart/osize/ostride into
    /tmp/oracle/out.<rank>.txt; this script only repackages those text files

@@ -92,7 +92,7 @@ def test_mpi_harness_compiles_and_links(built, tmp_path):
     exe = tmp_path / "run-fft-mpi"
     cmd = ["gcc", "-std=gnu11", "-O2", "-Wall", "-DOFFT_HARNESS_MPI", "-I" + os.path.join(ROOT, "include"), "-I/opt/conda/include",
            "-o", str(exe), os.path.join(ROOT, "harness", "run-fft.c"), "-L" + os.path.join(ROOT, "offt_amd"), "-loffthip",
-           "-L/opt/rocm/lib", "-lamdhip64", "/opt/conda/lib/libmpi.so", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "offt_amd"),
+           "-L/opt/rocm/lib", "-lamdhip64", "/opt/conda/lib/libmpi.so", "-lm", "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath," + os.path.join(ROOT, "offt_amd"),
            "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/conda/lib"]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert out.returncode == 0, out.stdout.decode()

@@ -1,6 +1,10 @@
-"""Pin the oracle (CPU restatement of offt-compute.c) BEFORE it is trusted as the checker:
-against the reference's own recorded outputs (tests/golden/ref_*.npz, survey_recorded.json)
-and against numpy.fft (pocketfft) as an independent second oracle."""
+"""Check the oracle (CPU restatement of offt-compute.c) BEFORE it is used as the checker.
+
+PARITY UNPINNED vs a reference build: the reference has no tests or golden vectors and cannot be built here (no FFTW).
+Numerics are pinned by numpy.fft (pocketfft) full grids and the closed-form ramp; the decomposition, default
+parameters and layouts by restating offt-compute.c, corroborated by values the survey stage recorded from a run of the
+reference linked against stand-in FFTW headers + MKL (tests/golden/ref_*.npz, survey_recorded.json -- a stand-in
+build, kept as corroboration, not as reference truth)."""
 import json
 import os
 
@@ -25,7 +29,8 @@ def test_fft1d_any_length():
 
 
 def test_reference_dump_18cube_6ranks():
-    """Full-grid output of the compiled reference (survey run): N=18, 6 ranks, p1=2, S=1."""
+    """Full-grid output of the survey's STAND-IN build of the reference (declarations-only FFTW headers + MKL):
+    N=18, 6 ranks, p1=2, S=1 -- corroboration, not a pin."""
     d = np.load(os.path.join(G, "ref_n18_p6_p1-2_S1.npz"))
     g, comms, v = O.world_fft(18, 18, 18, 6, kind=1, P1=2, S=1)
     ref = np.full((18, 18, 18), np.nan + 0j)
