@@ -391,6 +391,7 @@ typedef struct hip_state {
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
   size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
   int Tz2, H2;           /* pencil schedule, phase 2: z-chunk thickness (T2) and number of chunks of exchange 2 / FFTx */
+  int pencil_yc;         /* pencil exchange volumes laid out y- / x-contiguous (two strided sides instead of four), see execute_pipeline() */
   void **ev_a2;          /* per z-chunk: the chunk's share of every x-tile has arrived (exchange 2) */
   int uses_rccl;         /* this plan exchanges over RCCL communicators (watched while waiting) */
   int skip_mask;         /* diagnostics (offt_hip_set_debug_skip): 1 = no FFT passes, 2 = no exchanges */
@@ -611,6 +612,9 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   st->Tz2 = Tz;
   st->H2 = (c->M3 + Tz - 1) / Tz;
   st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
+  /* contiguous-line layouts of both exchange volumes need even x and z blocks made of whole tiles / chunks */
+  st->pencil_yc = c->b1 == 0 && c->b3 == 0 && c->M1 % st->T == 0 && c->M3 % Tz == 0 &&
+                  !(getenv("OFFT_PENCIL_ZC_LAYOUT") && atoi(getenv("OFFT_PENCIL_ZC_LAYOUT")));
   st->recv2 = be->dmalloc(st->blk2 * c->p1 * st->esz);
   st->send2 = st->x2 ? be->dmalloc(st->blk2 * c->p1 * st->esz) : st->recv2;
   if (!st->recv2 || !st->send2) return -1;
@@ -1560,8 +1564,13 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         d.ncols = c->m2; d.nb1 = myT;
         d.in_axis_stride = 1; d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.in_contig = 1;
-        d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
-        d.out_contig = 1;
+        if (st->pencil_yc) { /* send block [x_t][z_l][y]: 128-B runs of 8 y at a pitch of one y-line */
+          d.out_axis_stride = c->M2; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M3 * c->M2;
+          d.out_contig = 0;
+        } else {             /* send block [x_t][y][z-run] */
+          d.out_axis_stride = 1; d.out_col_stride = c->M3; d.out_b1_stride = (long long)c->M2 * c->M3;
+          d.out_contig = 1;
+        }
         if (p2 > 1) { /* peer a owns z in [a*F3, ..): offt-compute.c:1015-1027 */
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
@@ -1588,7 +1597,29 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
       if (st->x1) be->stream_wait(s, st->ev_a1[r]);
-      for (int part = 0; part < 2 && myT > 0; part++) {
+      if (st->pencil_yc && myT > 0) {
+        /* whole y-lines out of the receive blocks [x_t][z_l][y_l] (runs of F2 per peer), columns = x_t, into the
+         * column-exchange volume [chunk][peer][x-tile][z in chunk][y_l][x_t]: x contiguous, one (chunk, peer, tile)
+         * block = one message of exchange 2 */
+        const size_t B2 = (size_t)Tz * c->M4 * T;
+        offt_pass_desc d;
+        desc_init(&d, st, Ny, dir, 1);
+        d.ncols = myT; d.nb1 = Tz; d.nb2 = H;
+        d.in_axis_stride = 1; d.in_contig = 1;
+        d.in_col_stride = (long long)c->M3 * c->M2; d.in_b1_stride = c->M2; d.in_b2_stride = (long long)Tz * c->M2;
+        if (p2 > 1) {
+          d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0;
+          d.in_block_stride = (long long)st->blk1;
+        }
+        d.out_axis_stride = T; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * T;
+        d.out_b2_stride = (long long)p1 * st->ntiles * B2;
+        if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
+          d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
+          d.out_block_stride = (long long)st->ntiles * B2;
+        }
+        if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * B2 * esz, s, 0)) return -1;
+      }
+      for (int part = 0; part < 2 && myT > 0 && !st->pencil_yc; part++) {
         /* the chunks this rank fills completely go in one launch (chunk = second batch dimension), the ragged last
          * chunk (m3 not a multiple of T2) in another */
         const int h0 = part == 0 ? 0 : Hf, nh = part == 0 ? Hf : (c->m3 > Hf * Tz ? 1 : 0);
@@ -1631,7 +1662,9 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
             for (int a = 0; a < p1; a++) {
               const int e = hh * p1 + a;
               int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
-              const size_t off = ((size_t)a * st->blk2 + (size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz;
+              const size_t off = st->pencil_yc
+                                     ? (((size_t)h * p1 + a) * st->ntiles + k) * (size_t)Tz * c->M4 * T * esz
+                                     : ((size_t)a * st->blk2 + (size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz;
               pr[e] = peers2[a];
               sp[e] = (char *)st->send2 + off;
               rp[e] = (char *)st->recv2 + off;
@@ -1656,15 +1689,27 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     if (nz <= 0 || c->m4 <= 0) continue;
     offt_pass_desc d;
     desc_init(&d, st, Nx, dir, 0);
+    d.out_axis_stride = c->ostride[0];
+    d.out_contig = (c->ostride[0] == 1);
+    d.scale = st->out_scale;
+    if (st->pencil_yc) {
+      /* whole x-lines: x = (peer, tile, x_t) and the blocks (peer, tile) of a chunk are consecutive, so one split of length
+       * T addresses both levels; columns = y_l */
+      const size_t B2 = (size_t)Tz * c->M4 * T;
+      d.ncols = c->m4; d.nb1 = nz;
+      d.in_axis_stride = 1; d.in_contig = 1; d.in_col_stride = T; d.in_b1_stride = (long long)c->M4 * T;
+      d.in_split = T; d.in_block_stride = (long long)B2;
+      d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2];
+      if (run_pass(st, &d, (char *)st->recv2 + (size_t)h * p1 * st->ntiles * B2 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
+      continue;
+    }
     d.ncols = nz; d.nb1 = c->m4;
     d.in_axis_stride = (long long)c->M4 * tzh; d.in_col_stride = 1; d.in_b1_stride = tzh;
     if (p1 > 1) { /* peer a owns x in [a*F1, ..): offt-compute.c:2432-2450 */
       d.in_split = c->F1; d.in_split_nfloor = c->b1 ? p1 - c->b1 : 0;
       d.in_block_stride = (long long)st->blk2;
     }
-    d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
-    d.out_contig = (c->ostride[0] == 1);
-    d.scale = st->out_scale;
+    d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
     if (run_pass(st, &d, (char *)st->recv2 + (size_t)z0 * MM * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
   }
   be->event_record(st->evp[3], s);

@@ -70,7 +70,11 @@ def test_eight_ranks_one_gpu_bench_meshes(built, tmp_path):
              dict(N=[256, 256, 256], params=dict(P1=8)), dict(N=[256, 256, 256], params=dict(P1=2), env=dict(OFFT_MIN_MSG=0)),
              dict(N=[100, 72, 90], params=dict(P1=2, T1=7, T2=5)), dict(N=[100, 72, 90], params=dict(P1=1)),
              dict(N=[128, 128, 128], params=dict(), inv=1), dict(N=[128, 128, 128], params=dict(P1=1), inv=1),
-             dict(N=[128, 64, 256], params=dict(P1=4), r2c=1), dict(N=[128, 128, 128], params=dict(P1=4, S=1, T2=8))]
+             dict(N=[128, 64, 256], params=dict(P1=4), r2c=1), dict(N=[128, 128, 128], params=dict(P1=4, S=1, T2=8)),
+             # the first-version exchange-volume layouts (kept for uneven grids) on an even grid
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
+             dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=4), env=dict(OFFT_SLAB_XC_LAYOUT=1)),
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), inv=1)]
     s = run_thread_world(8, cases, tmp_path)
     assert s[1]["mesh"] == [2, 4]  # offt-compute.c:3138-3139: the largest divisor of p that is <= sqrt(p)
 

@@ -197,6 +197,14 @@ def test_gloo_world2(built, tmp_path):
              dict(N=[9, 7, 11], params=dict(P1=2, T1=4, T2=4, W2=0, S=1)), dict(N=[8, 8, 10], params=dict(P1=2, T2=3), eq=1),
              dict(N=[8, 6, 12], params=dict(P1=2, T1=3, T2=2), r2c=1), dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3), inv=1),
              dict(N=[9, 7, 11], params=dict(P1=1, T1=2, T2=3, S=1)),
+             # both exchange-volume layouts of each schedule on the same even grid: contiguous lines (default) and the
+             # first version (forced), incl. r2c, inverse and the x-y-z / y-z-x output layouts
+             dict(N=[8, 8, 14], params=dict(P1=2, T1=2, T2=4), r2c=1), dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=2, S=1)),
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=4), eq=1), dict(N=[8, 8, 8], params=dict(P1=2, T1=4, T2=2), inv=1),
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=2), env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
+             dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=2), inv=1, env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
+             dict(N=[8, 8, 8], params=dict(P1=1, T1=2, T2=2), env=dict(OFFT_SLAB_XC_LAYOUT=1)),
+             dict(N=[8, 8, 8], params=dict(P1=1, T1=2, T2=2), inv=1),
              # the defaults' own tiling (no 4 MiB message floor): T1 = M1/16, T2 = M3/16 merged to <= 8 chunks
              dict(N=[32, 16, 32], params=dict(P1=2), env=dict(OFFT_MIN_MSG=0)),
              dict(N=[32, 16, 32], params=dict(P1=1), env=dict(OFFT_MIN_MSG=0))]
@@ -208,7 +216,9 @@ def test_gloo_world4(built, tmp_path):
              dict(N=[8, 8, 8], params=dict(P1=1, T1=3)), dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1)),
              dict(N=[6, 10, 7], params=dict(P1=2, S=1)),
              dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1, T2=2)), dict(N=[12, 8, 10], params=dict(P1=4, T1=1, T2=3)),
-             dict(N=[10, 6, 9], params=dict(P1=2, T1=2, T2=2), inv=1), dict(N=[16, 16, 16], params=dict(), env=dict(OFFT_MIN_MSG=0))]
+             dict(N=[10, 6, 9], params=dict(P1=2, T1=2, T2=2), inv=1), dict(N=[16, 16, 16], params=dict(), env=dict(OFFT_MIN_MSG=0)),
+             dict(N=[16, 8, 12], params=dict(P1=2, T1=2, T2=3)), dict(N=[16, 8, 12], params=dict(P1=4, T1=2, T2=4, S=1), inv=1),
+             dict(N=[16, 8, 12], params=dict(P1=2, T1=4, T2=2), env=dict(OFFT_PENCIL_ZC_LAYOUT=1))]
     _run_world(4, cases, tmp_path)
 
 
