@@ -61,6 +61,10 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream);
  *    no timing events are recorded then, so back-to-back small transforms pay
  *    for the kernel launches only.                                              */
 void offt_hip_set_async(struct _offt_plan *po, int async);
+/* asynchronous mode: wait for everything enqueued on the plan so far.  Like the end of a synchronous execute the wait
+ * is bounded (OFFT_EXEC_TIMEOUT) and polls the RCCL communicators for asynchronous errors; returns 0, or -1 with
+ * t[ALL] = 99999999 and the text in offt_hip_last_error().                                                        */
+int offt_hip_wait(struct _offt_plan *po);
 /* diagnostics for launchers: leave out the FFT passes (mask 1: exchange-only time) or the exchanges (mask 2:
  * compute-only time) of the multi-rank schedules.  Results are meaningless while a mask is set; 0 restores.       */
 void offt_hip_set_debug_skip(struct _offt_plan *po, int mask);

@@ -126,6 +126,8 @@ def bind(L):
     L.offt_hip_world_count.restype = i
     L.offt_hip_link_probe.restype = C.c_double
     L.offt_hip_link_probe.argtypes = [i, i, C.c_longlong, i]
+    L.offt_hip_wait.restype = i
+    L.offt_hip_wait.argtypes = [PP]
     L.offt_hip_set_debug_skip.restype = None
     L.offt_hip_set_debug_skip.argtypes = [PP, i]
     L._offt_bound = True

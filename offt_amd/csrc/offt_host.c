@@ -1836,6 +1836,15 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
   t[ALL] = wall_seconds() - t0;
 }
 
+/* asynchronous mode (offt_hip_set_async): wait for everything enqueued so far -- the same bounded, error-polling
+ * wait a synchronous execute ends with.  0 on success; on failure the communicators are aborted and t[ALL] carries the
+ * reference's failure marker. */
+int offt_hip_wait(struct _offt_plan *po) {
+  hip_state *st = (hip_state *)po->hip_state;
+  if (wait_compute(st)) { po->t[ALL] = 99999999.0; return -1; }
+  return 0;
+}
+
 void offt_3d_execute(struct _offt_plan *po, double *in, double *out, int is_tuning) {
   (void)is_tuning;
   offt_3d_execute_dir(po, in, out, -1);
