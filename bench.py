@@ -396,7 +396,10 @@ def rank_main(args):
         try:
             # the reference's default mesh: the largest divisor of p that is <= sqrt(p) (2 x 4 at 8 ranks)
             p1_def = max(d for d in range(1, int(math.isqrt(world)) + 1) if world % d == 0)
-            if p1_def != p1_head:
+            force_pencil = bool(int(os.environ.get("OFFT_BENCH_FORCE_PENCIL", "0")))  # one-GPU rehearsal of this branch
+            if p1_def != p1_head or force_pencil:
+                if force_pencil:
+                    os.environ["OFFT_NO_SLAB_LAYOUT"] = "1"
                 po2, data2 = make_plan(p1_def)
                 c2 = api.comm_dict(po2)
                 ksteps = max(2, min(5, steps))
