@@ -100,11 +100,32 @@ def main():
             v = list(po.contents.params.contents.v)
             dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64 if prec == api.F64 else torch.float32, device="cuda")
             torch.cuda.synchronize()
-            if L.offt_hip_fill_input(po, dev.data_ptr(), 1):
+            ramp = case.get("check") == "ramp"
+            if L.offt_hip_fill_input(po, dev.data_ptr(), 0 if ramp else 1):
                 raise RuntimeError("fill failed")
+            ct = np.complex128 if prec == api.F64 else np.complex64
+            if ramp:
+                # full-size property check (no host copy of the grid): energy before / after, closed-form spot values
+                torch.cuda.synchronize()
+                e_in = float(dev.double().square().sum())
+                bar.wait()
+                api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+                e_out = float(dev.double().square().sum())
+                cv = torch.view_as_complex(dev.view(-1, 2))
+                spots = {}
+                os_, oz, ost = c["ostart"], c["osize"], c["ostride"]
+                for g in case["spots"]:
+                    loc = [g[d] - os_[d] for d in range(3)]
+                    if all(0 <= loc[d] < oz[d] for d in range(3)):
+                        z = complex(cv[loc[0] * ost[0] + loc[1] * ost[1] + loc[2] * ost[2]])
+                        spots[",".join(map(str, g))] = [z.real, z.imag]
+                bar.wait()
+                api.offt_3d_fin(po)
+                L.offt_hip_test_set_transport(None, 0, 1)
+                results[(ci, rank)] = {"comm": c, "v": v, "e_in": e_in, "e_out": e_out, "spots": spots}
+                return
             bar.wait()
             api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
-            ct = np.complex128 if prec == api.F64 else np.complex64
             res = {"comm": c, "v": v, "out": dev.cpu().numpy().view(ct).copy()}
             if case.get("inv"):
                 bar.wait()
@@ -140,6 +161,33 @@ def main():
         shape = tuple(case["N"])
         r2c = case.get("r2c", 0)
         f32 = bool(case.get("f32"))
+        if case.get("check") == "ramp":
+            E = float(np.prod(shape))
+            e_in = sum(results[(ci, r)]["e_in"] for r in range(size))
+            e_out = sum(results[(ci, r)]["e_out"] for r in range(size))
+            n = shape[0]
+            worst = abs(e_out / (E * e_in) - 1.0)   # Parseval, unnormalised forward transform
+            got = {}
+            for r in range(size):
+                got.update(results[(ci, r)]["spots"])
+            assert len(got) == len(case["spots"]), (sorted(got), case["spots"])
+            for key, (re, im) in got.items():
+                gx, gy, gz = map(int, key.split(","))
+                nz_axes = [(gx, 100.0), (gy, 10.0), (gz, 1.0)]
+                k = [(kk, w) for kk, w in nz_axes if kk]
+                if not k:
+                    want = n ** 3 * 111 * (n - 1) / 2
+                elif len(k) == 1:
+                    want = k[0][1] * n ** 3 * (-0.5 + 0.5j / np.tan(np.pi * k[0][0] / n))
+                else:
+                    want = 0.0
+                scale = abs(want) if want else n ** 3 * 111 * (n - 1) / 2
+                worst = max(worst, abs(complex(re, im) - want) / scale)
+            rec = {"case": case, "mesh": [results[(ci, 0)]["comm"]["p1"], results[(ci, 0)]["comm"]["p2"]], "rel_numpy": worst,
+                   "v": results[(ci, 0)]["v"], "tol": 5e-6 if f32 else 1e-12}
+            summary.append(rec)
+            print(json.dumps({k: rec[k] for k in rec if k != "v"}), flush=True)
+            continue
         oshape = (shape[0], shape[1], shape[2] // 2 + 1) if r2c else shape
         G = np.full(oshape, np.nan + 0j)
         for r in range(size):

@@ -79,6 +79,19 @@ def test_eight_ranks_one_gpu_bench_meshes(built, tmp_path):
     assert s[1]["mesh"] == [2, 4]  # offt-compute.c:3138-3139: the largest divisor of p that is <= sqrt(p)
 
 
+def test_config3_full_size_eight_ranks_one_gpu(built, tmp_path):
+    """BASELINE configs[3] at FULL size on one GPU: 1024^3 double-complex over 8 ranks (threads sharing the card, 8 GiB of
+    buffers each), the bench's 1x8 mesh and the reference-default 2x4 pencil mesh.  Checked through size-independent
+    properties: Parseval over all ranks, and the closed form of the harness ramp at spots on the three axes, off the axes
+    and in the last rank's block (cube side n: X[0,0,0] = n^3 111 (n-1)/2, X[0,0,k] = n^3 (-1/2 + i/2 cot(pi k/n)))"""
+    n = 1024
+    spots = [[0, 0, 0], [0, 0, 1], [0, 0, 3], [0, 0, 1023], [0, 5, 0], [0, 1000, 0], [7, 0, 0], [513, 0, 0], [1, 1, 1], [1023, 1023, 1023],
+             [0, 511, 640], [300, 0, 900]]
+    cases = [dict(N=[n, n, n], params=dict(P1=1), check="ramp", spots=spots), dict(N=[n, n, n], params=dict(), check="ramp", spots=spots)]
+    s = run_thread_world(8, cases, tmp_path)
+    assert s[0]["mesh"] == [1, 8] and s[1]["mesh"] == [2, 4]
+
+
 def test_single_precision_worlds_one_gpu(built, tmp_path):
     """BASELINE configs[4] as far as one GPU can take it: single-precision worlds of 2 and 8 ranks (slab, default
     pencil mesh, uneven per-peer blocks), tolerance rel-L2 <= 5e-6"""
