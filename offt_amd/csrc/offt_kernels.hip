@@ -383,7 +383,7 @@ Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = f
 }
 
 // ---------------------------------------------------------------------------
-// Plan-time specialisation.  A length without a precompiled panel kernel whose prime factors are <= 13 gets
+// Plan-time specialisation.  A length without a precompiled panel kernel whose prime factors are <= 31 gets
 // its own fft_panelx_k instances at offt_hipk_prepare(): the device part of offt_panel.hpp travels inside
 // the library as a string, a shape (radix order, threads per line, panel width) is picked with the scoring of
 // tools/dev_sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours and the two real-input ones (2-4 s in all) and the
@@ -437,8 +437,9 @@ bool rtc_load() {
 
 struct Shape { int tpl, r0, r1, r2, cols; double score; int emax; size_t lds; };
 
+// lengths the panel kernels can factor into register radices <= 32: every prime factor <= 31
 bool smooth13(int n) {
-  for (int p : {2, 3, 5, 7, 11, 13}) while (n % p == 0) n /= p;
+  for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31}) while (n % p == 0) n /= p;
   return n == 1;
 }
 int cdiv_i(int a, int b) { return (a + b - 1) / b; }
@@ -732,7 +733,7 @@ int offt_hipk_prepare(int n, int precision) {
   if (n < 1) { snprintf(g_err, sizeof g_err, "offt_hipk_prepare: bad n=%d", n); return -1; }
   Tables tb;
   if (get_tables(n, precision, tb, true)) return -1;
-  // a 13-smooth length of 256 .. 4096 points without a precompiled panel kernel gets one now (best effort)
+  // a 31-smooth length of 256 .. 4096 points without a precompiled panel kernel gets one now (best effort)
   if (rtc_enabled() && n >= 256 && n <= 4096 && smooth13(n) && !find_variant(n, precision, true, true, -1)) (void)rtc_build(n, precision);
   // a length neither a panel kernel nor the any-length kernel (two ping-pong images of one line in LDS) can take is
   // refused HERE, at plan time: offt_3d_init returns NULL instead of every execute failing

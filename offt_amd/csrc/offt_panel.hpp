@@ -536,8 +536,9 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
 constexpr int first_factor(int r) {
   return r % 2 == 0 ? 2 : (r % 3 == 0 ? 3 : (r % 5 == 0 ? 5 : (r % 7 == 0 ? 7 : (r % 11 == 0 ? 11 : (r % 13 == 0 ? 13 : r)))));
 }
-// register radices: products of the primes 2 .. 13
-constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 13 && smooth235(r / first_factor(r))); }
+// register radices (<= 32): products of the primes 2 .. 13, or one of the primes 17 .. 31 (a radix <= 32 with such a
+// factor is that prime itself; first_factor returns it)
+constexpr bool smooth235(int r) { return r <= 1 ? true : (first_factor(r) <= 31 && smooth235(r / first_factor(r))); }
 // X[k] of dft_mixed<R> is left in v[perm_mixed(R, k)]
 constexpr int perm_mixed(int r, int k) {
   if (r <= 1) return 0;
@@ -572,7 +573,8 @@ template <typename T, int R>
 __device__ __forceinline__ void dft_mixed(cx<T> *v) {
   if constexpr (R > 1) {
     constexpr int p = first_factor(R), m = R / p;
-    static_assert(p == 2 || p == 3 || p == 5 || p == 7 || p == 11 || p == 13, "register radix must be a product of primes <= 13");
+    static_assert(p == 2 || p == 3 || p == 5 || p == 7 || p == 11 || p == 13 || p == 17 || p == 19 || p == 23 || p == 29 || p == 31,
+                  "register radix must be a product of primes <= 13 or a prime <= 31");
     static_for<0, m>([&](auto bb) {
       constexpr int b = decltype(bb)::value;
       if constexpr (p == 2) {
@@ -603,7 +605,7 @@ __device__ __forceinline__ void dft_mixed(cx<T> *v) {
         v[3 * m + b] = mulwr<T, R, 3 * b>(cx<T>{p2.x - q2.y, p2.y + q2.x});  // p2 + i q2
         v[4 * m + b] = mulwr<T, R, 4 * b>(cx<T>{p1.x - q1.y, p1.y + q1.x});  // p1 + i q1
       } else {
-        // any odd prime p (7, 11, 13): X_k = x0 + sum_j cos(2 pi j k/p) s_j - i sum_j sin(2 pi j k/p) d_j with
+        // any odd prime p (7, 11, 13; 17 .. 31 in plan-time instances): X_k = x0 + sum_j cos(2 pi j k/p) s_j - i sum_j sin(2 pi j k/p) d_j with
         // s_j = x_j + x_(p-j), d_j = x_j - x_(p-j), j = 1..(p-1)/2; X_(p-k) is the same with + i.  The path is
         // HBM-bound, so the h^2 multiply-adds are not worth a Winograd factorisation.
         constexpr int h = (p - 1) / 2;
@@ -680,7 +682,7 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
   constexpr int NT = Cfg::NT, NSTAGE = Cfg::NSTAGE, LSTRIDE = Cfg::LSTRIDE, EMAX = Cfg::EMAX;
   constexpr int PADDIV = Cfg::PADDIV;
   static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
-  static_assert(smooth235(R0) && smooth235(R1) && smooth235(R2), "radices must be products of primes <= 13");
+  static_assert(smooth235(R0) && smooth235(R1) && smooth235(R2), "radices must be products of primes <= 13, or primes <= 31");
   static_assert(R0 <= 32 && R1 <= 32 && R2 <= 32, "register radix <= 32");
 
   extern __shared__ __align__(16) unsigned char smem[];
