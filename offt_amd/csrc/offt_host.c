@@ -485,10 +485,12 @@ static int hb_a2a(void *ctx, int which, int npeers, const int *peer_rank_in_comm
   ncclComm_t cm = which == 1 ? st->comm1 : (which == 2 ? st->comm2 : G.world);
   if (!cm) { SET_ERR("exchange %d without a communicator", which); return -1; }
   NCHECK(R.GroupStart(), return -1);
-  for (int a = 0; a < npeers; a++) {
-    if (sendbytes[a]) NCHECK(R.Send(sendp[a], sendbytes[a], NCCL_INT8, peer_rank_in_comm[a], cm, (hipStream_t)stream), return -1);
-    if (recvbytes[a]) NCHECK(R.Recv(recvp[a], recvbytes[a], NCCL_INT8, peer_rank_in_comm[a], cm, (hipStream_t)stream), return -1);
+  int rc = 0;
+  for (int a = 0; a < npeers && !rc; a++) {
+    if (sendbytes[a]) NCHECK(R.Send(sendp[a], sendbytes[a], NCCL_INT8, peer_rank_in_comm[a], cm, (hipStream_t)stream), rc = -1);
+    if (!rc && recvbytes[a]) NCHECK(R.Recv(recvp[a], recvbytes[a], NCCL_INT8, peer_rank_in_comm[a], cm, (hipStream_t)stream), rc = -1);
   }
+  if (rc) { (void)R.GroupEnd(); return -1; } /* never leave a group open behind a failed call */
   NCHECK(R.GroupEnd(), return -1);
   return 0;
 }

@@ -39,11 +39,16 @@
 #include <hip/hiprtc.h>
 #include "offt_hipk.h"
 #include "offt_panel.hpp"
+#include "offt_bluestein.hpp"
 #include "offt_rtc_source.inc"
 
 namespace offtk {
 std::vector<Variant> &registry() {
   static std::vector<Variant> r;
+  return r;
+}
+std::vector<BlueVariant> &blue_registry() {
+  static std::vector<BlueVariant> r;
   return r;
 }
 }  // namespace offtk
@@ -349,6 +354,7 @@ void build_registry() {
   reg_mixed_f64_e();
   reg_mixed_f32_a();
   reg_mixed_f32_b();
+  reg_bluestein_all();
 #endif
 }
 
@@ -664,6 +670,69 @@ int get_tables(int n, int prec, Tables &out, bool create) {
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// ---------------------------------------------------------------------------
+// Bluestein (offt_bluestein.hpp): per (n, precision) the chirp a[n] = exp(-i pi n^2 / n_len) and the spectrum
+// B^ = FFT_M(b wrapped) / M, b[m] = exp(+i pi m^2 / n_len), M = the power of two >= 2 n_len - 1.
+// ---------------------------------------------------------------------------
+struct BlueTab { void *chirp = nullptr, *bhat = nullptr; int m = 0; };
+std::mutex g_blue_mu;
+std::map<std::pair<int, int>, BlueTab> g_blue;
+
+bool blue_enabled() {
+  static const bool on = !(getenv("OFFT_BLUESTEIN") && atoi(getenv("OFFT_BLUESTEIN")) == 0);
+  return on;
+}
+int blue_m(int n) {
+  int m = 256;
+  while (m < 2 * n - 1) m <<= 1;
+  return m;
+}
+BlueVariant *find_blue(int m, int prec, bool inc, bool outc) {
+  std::call_once(g_reg_once, build_registry);
+  for (auto &b : blue_registry())
+    if (b.m == m && b.prec == prec && b.inc == inc && b.outc == outc) return &b;
+  return nullptr;
+}
+bool blue_lookup(int n, int prec, BlueTab *out) {
+  std::lock_guard<std::mutex> lk(g_blue_mu);
+  auto it = g_blue.find(std::make_pair(n, prec));
+  if (it == g_blue.end()) return false;
+  *out = it->second;
+  return true;
+}
+
+template <typename T>
+int blue_build(int n, int prec, BlueTab &tb) {
+  using V2 = typename vec2<T>::type;
+  const int m = blue_m(n);
+  const long double pi = 3.14159265358979323846264338327950288419716939937510L;
+  // angle pi k^2 / n with k^2 reduced mod 2n in integers: exact argument reduction
+  auto ang = [&](long long k) { return pi * (long double)((k * k) % (2LL * n)) / (long double)n; };
+  std::vector<V2> a(n), b(m);
+  for (int k = 0; k < n; ++k) { a[k].x = (T)cosl(ang(k)); a[k].y = (T)(-sinl(ang(k))); }
+  for (int k = 0; k < m; ++k) { b[k].x = 0; b[k].y = 0; }
+  for (int k = 0; k < n; ++k) {
+    V2 w; w.x = (T)cosl(ang(k)); w.y = (T)sinl(ang(k));
+    b[k] = w;
+    if (k) b[m - k] = w;
+  }
+  HIPK_CHECK(hipMalloc(&tb.chirp, a.size() * sizeof(V2)));
+  HIPK_CHECK(hipMemcpy(tb.chirp, a.data(), a.size() * sizeof(V2), hipMemcpyHostToDevice));
+  HIPK_CHECK(hipMalloc(&tb.bhat, b.size() * sizeof(V2)));
+  HIPK_CHECK(hipMemcpy(tb.bhat, b.data(), b.size() * sizeof(V2), hipMemcpyHostToDevice));
+  tb.m = m;
+  // B^ = FFT_M(b) / M with the M-point panel kernel itself, in place, one line
+  if (offt_hipk_prepare(m, prec)) return -1;
+  offt_pass_desc d;
+  memset(&d, 0, sizeof d);
+  d.n = m; d.precision = prec; d.direction = -1; d.ncols = 1; d.nb1 = d.nb2 = 1;
+  d.in_axis_stride = d.out_axis_stride = 1; d.in_col_stride = d.out_col_stride = m;
+  d.in_contig = d.out_contig = 1; d.variant = -1; d.scale = 1.0 / (double)m;
+  if (offt_hipk_fft_pass(&d, tb.bhat, tb.bhat, nullptr)) return -1;
+  HIPK_CHECK(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
 // XCD-aware panel order (panel_of_block): runs of G = 32 neighbouring panels per XCD by default,
 // OFFT_XCD_REMAP=0 turns it off, OFFT_XCD_REMAP=<power of two> sets G
 void xcd_order(long long nblk, unsigned *lim, unsigned *gshift) {
@@ -725,7 +794,8 @@ int offt_hipk_variant_info(int n, int precision, int variant, int *elems_per_thr
 
 const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
   const Variant *v = pick_variant(d);
-  if (!v) return "fft_mixed_k";
+  BlueTab bt;
+  if (!v) return (!d->real_input && blue_lookup(d->n, d->precision, &bt) && find_blue(bt.m, d->precision, d->in_contig != 0, d->out_contig != 0)) ? "fft_bluestein_k" : "fft_mixed_k";
   return v->mixed ? "fft_panelx_k" : "fft_panel_k";
 }
 
@@ -735,6 +805,20 @@ int offt_hipk_prepare(int n, int precision) {
   if (get_tables(n, precision, tb, true)) return -1;
   // a 31-smooth length of 256 .. 4096 points without a precompiled panel kernel gets one now (best effort)
   if (rtc_enabled() && n >= 256 && n <= 4096 && smooth13(n) && !find_variant(n, precision, true, true, -1)) (void)rtc_build(n, precision);
+  // a length without any register kernel (a prime factor > 31, or outside 256 .. 4096 and not precompiled) runs as a
+  // Bluestein convolution on a power-of-two panel kernel when 2n - 1 <= 4096
+  // (lengths built from primes <= 13 stay on the any-length kernel, whose small-radix stages are whole butterflies)
+  int maxp = 1;
+  { int m = n; for (int p = 2; p * p <= m; ++p) while (m % p == 0) { maxp = p > maxp ? p : maxp; m /= p; } if (m > 1 && m > maxp) maxp = m; }
+  if (blue_enabled() && n >= 32 && n <= 2048 && maxp > 13 && !find_variant(n, precision, true, true, -1) && find_blue(blue_m(n), precision, true, true)) {
+    std::lock_guard<std::mutex> lk(g_blue_mu);
+    if (!g_blue.count(std::make_pair(n, precision))) {
+      BlueTab bt;
+      const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
+      if (rc) return -1;
+      g_blue[std::make_pair(n, precision)] = bt;
+    }
+  }
   // a length neither a panel kernel nor the any-length kernel (two ping-pong images of one line in LDS) can take is
   // refused HERE, at plan time: offt_3d_init returns NULL instead of every execute failing
   const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
@@ -755,8 +839,13 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     return 0;
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
-  if (Variant *v = pick_variant(d)) {
+  Variant *v = pick_variant(d);
+  BlueTab bt;
+  BlueVariant *bv = nullptr;
+  if (!v && !d->real_input && blue_lookup(d->n, d->precision, &bt)) bv = find_blue(bt.m, d->precision, d->in_contig != 0, d->out_contig != 0);
+  if (v || bv) {
     PassArgs a;
+    const int cols = v ? v->cols : bv->cols;
     a.in_axis = d->in_axis_stride; a.in_col = d->in_col_stride; a.in_b1 = d->in_b1_stride; a.in_b2 = d->in_b2_stride;
     a.out_axis = d->out_axis_stride; a.out_col = d->out_col_stride; a.out_b1 = d->out_b1_stride; a.out_b2 = d->out_b2_stride;
     a.in_blk = d->in_block_stride; a.out_blk = d->out_block_stride;
@@ -771,13 +860,26 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.in_inv1 = 1.0f / (float)(d->in_split + 1);
     a.out_inv1 = 1.0f / (float)(d->out_split + 1);
     a.ncols = d->ncols;
-    a.ncp = (d->ncols + v->cols - 1) / v->cols;
+    a.ncp = (d->ncols + cols - 1) / cols;
     a.nb1 = d->nb1;
     a.conj = d->direction > 0;
     a.scale = d->scale;
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
     xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
+    if (bv) {  // Bluestein: the M-point panel machinery on a line of n points (offt_bluestein.hpp)
+      Tables tm;
+      if (get_tables(bt.m, d->precision, tm, false)) return -1;
+      int nlen = d->n;
+      void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tm.full, (void *)&bt.chirp, (void *)&bt.bhat, (void *)&nlen};
+      if (!bv->attr_set) {
+        if (bv->lds > 48 * 1024)
+          HIPK_CHECK(hipFuncSetAttribute(bv->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bv->lds));
+        bv->attr_set = true;
+      }
+      HIPK_CHECK(hipLaunchKernel(bv->fn, dim3((unsigned)nblk), dim3(bv->threads), args, bv->lds, st));
+      return 0;
+    }
     // every panel kernel stages its twiddles from the exact full-wave table w^m, m < n (the quarter- and half-wave
     // tables they keep in LDS are prefixes of it)
     void *args[] = {(void *)&a, (void *)&in, (void *)&out, (void *)&tb.full};

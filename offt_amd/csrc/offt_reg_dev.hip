@@ -20,6 +20,17 @@ void reg_dev() {
   reg_variant<float, 2048, 32, 16, 16, 8, 16, true>(3, 0);
   reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(4, 0);
 #endif
+#ifdef OFFT_DEV_R2F32  /* round 2: radix orders of the 2048-point single-precision kernel on 16-column panels */
+  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
+  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(1, F_CC);
+  reg_variant<float, 2048, 32, 32, 2, 32, 16, true>(2, 0);
+  reg_variant<float, 2048, 32, 32, 8, 8, 16, true>(3, 0);
+  reg_variant<float, 2048, 32, 8, 8, 32, 16, true>(4, 0);
+  reg_variant<float, 2048, 32, 16, 16, 8, 16, true>(5, 0);
+  reg_variant<float, 2048, 32, 8, 16, 16, 16, true>(6, 0);
+  reg_variant<float, 2048, 32, 16, 8, 16, 16, true>(7, 0);
+#endif
 #ifdef OFFT_DEV_512
   reg_variant<double, 512, 16, 16, 16, 2, 8, true>(0, F_ALL);
   reg_variant<double, 512, 16, 16, 8, 4, 8, true>(1, 0);

@@ -102,7 +102,7 @@ REPS = int(os.environ.get("OFFT_TEST_DESC_REPS", "6"))
 
 
 @pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 6, 12, 15, 18, 30, 45, 90, 100, 127, 384,
-                               768, 1000, 448, 896, 1001])
+                               768, 1000, 448, 896, 1001, 37, 254, 509, 1016, 1021, 2039])  # the last six: Bluestein
 def test_random_descriptors(libs, n):
     L, CB = libs
     rng = np.random.default_rng(1000 + n)
@@ -174,8 +174,10 @@ def test_split_routing(libs):
     assert name(1024, in_split=170, in_nfloor=2) == "fft_panelx_k"        # 1024 over 6 peers
     assert name(768, out_split=96) == "fft_panelx_k"
     assert name(1000, in_split=142, in_nfloor=1) == "fft_panelx_k"        # 1000 over 7 peers
-    assert name(127) == "fft_mixed_k"
+    assert L.offt_hipk_prepare(127, api.F64) == 0 and L.offt_hipk_prepare(127, api.F32) == 0
+    assert name(127) == "fft_bluestein_k"    # a prime: chirp-z on the 256-point panel machinery (round 2)
+    assert name(4099) == "fft_mixed_k"       # 2 n - 1 > 4096: the any-length kernel
     assert name(1024, out_split=341, out_nfloor=2, prec=api.F32) == "fft_panelx_k"  # f32 any-split instances (round 2)
     assert name(2048, in_split=292, in_nfloor=3, prec=api.F32) == "fft_panelx_k"    # 2048 over 7 peers, single precision
-    assert name(127, prec=api.F32) == "fft_mixed_k"
+    assert name(127, prec=api.F32) == "fft_bluestein_k"
 

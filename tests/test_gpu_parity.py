@@ -137,6 +137,39 @@ def test_plan_time_specialised_kernel(built, shape):
         check64(got, want)
 
 
+@pytest.mark.parametrize("shape", [(127, 8, 4), (4, 254, 6), (6, 4, 1016), (1021, 4, 2), (2, 2, 2039), (37, 74, 41), (508, 2, 127)])
+def test_bluestein_lengths(built, shape):
+    """lengths with a prime factor > 31 (FFTW takes any N): Bluestein's chirp-z on the power-of-two panel machinery,
+    one HBM round trip (offt_bluestein.hpp) -- every layout, inverse round trip, single precision"""
+    L = api.lib()
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft(shape, **layout)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)
+        check64(got, want)
+    got, _ = gpu_fft(shape, precision=api.F32)
+    want, _, _ = O.world_fft(*shape, 1, kind=1)
+    assert rel(got.astype(np.complex128), want) < TOL32
+    # forward then inverse gives the input back times E
+    po = api.offt_3d_init(*shape)
+    f = O.hash_field(*shape)
+    dev, idx = make_input(po, f)
+    x0 = dev.clone()
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+    back = dev.cpu().numpy().view(np.complex128)[idx].reshape(shape) / np.prod(shape)
+    api.offt_3d_fin(po)
+    assert rel(back, f) < TOL64
+    # the pass really ran on the Bluestein kernel
+    import ctypes as C
+    from test_gpu_descriptors import Desc
+    L.offt_hipk_kernel_name.restype = C.c_char_p
+    L.offt_hipk_kernel_name.argtypes = [C.POINTER(Desc)]
+    big = max(s for s in shape if any(s % p == 0 for p in range(37, s + 1) if all(p % q for q in range(2, int(p ** 0.5) + 1))))
+    d = Desc()
+    d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2, d.in_contig, d.out_contig, d.variant, d.scale = big, api.F64, -1, 8, 1, 1, 1, 1, -1, 1.0
+    assert L.offt_hipk_kernel_name(C.byref(d)) == b"fft_bluestein_k", big
+
+
 def test_mixed_radix_full_size_768_properties(built):
     """768^3 (3 * 2^8) on the mixed-radix panel kernel: Parseval, DC term, forward/inverse round trip"""
     n = 768
@@ -412,6 +445,30 @@ def test_r2c_forced_pipeline(built, monkeypatch):
         got, _ = gpu_fft(shape, is_r2c=1, **kw)
         want, _, _ = O.world_fft(*shape, 1, kind=1, is_r2c=1, **kw)
         check64(got, want)
+
+
+def test_mpi_harness_runs_one_rank(built, tmp_path):
+    """the MPI build of the harness (rank/size from MPI, RCCL id by MPI_Bcast: the reference's launch model,
+    run-fft.c:158-160) under mpiexec with the one rank a one-GPU box allows: same stdout lines and spot values"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists("/opt/conda/include/mpi.h") or not os.path.exists(mpiexec):
+        pytest.skip("no MPI in this image")
+    exe = tmp_path / "run-fft-mpi"
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-DOFFT_HARNESS_MPI", "-I" + os.path.join(root, "include"), "-I/opt/conda/include",
+                           "-o", str(exe), os.path.join(root, "harness", "run-fft.c"), "-L" + os.path.join(root, "offt_amd"), "-loffthip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "/opt/conda/lib/libmpi.so", "-lm", "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu",
+                           "-Wl,-rpath," + os.path.join(root, "offt_amd"), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/conda/lib"])
+    n = 128
+    out = subprocess.check_output([mpiexec, "-n", "1", str(exe), "-N", str(n), "-n", str(n), "-L", str(n), "-r", "2", "-v"],
+                                  stderr=subprocess.STDOUT, timeout=300).decode()
+    lines = out.splitlines()
+    assert any(l.startswith("@ FINAL") for l in lines) and any(l.startswith("t_min ") for l in lines), out
+    spots = [l for l in lines if l.startswith("p 0: 0 0 ")]
+    assert len(spots) == 4, out
+    assert float(spots[0].split(":")[2].split()[0]) == n ** 3 * 111 * (n - 1) / 2
 
 
 def test_harness_and_static_sweep(built, tmp_path):

@@ -113,7 +113,9 @@ def test_two_ranks_one_gpu(built, tmp_path):
              dict(N=[64, 64, 64], params=dict(P1=1), inv=1), dict(N=[64, 32, 16], params=dict(P1=2, T1=8), inv=1),
              # mixed-radix panel kernels with per-peer splits that are not powers of two (96 = 2 x 48, 120 = 2 x 60)
              dict(N=[96, 96, 96], params=dict(P1=1)), dict(N=[120, 96, 100], params=dict(P1=2), inv=1),
-             dict(N=[96, 120, 96], params=dict(P1=1), r2c=1)]
+             dict(N=[96, 120, 96], params=dict(P1=1), r2c=1),
+             # lengths with the prime factor 127: Bluestein passes addressing per-peer blocks (254 = 2 x 127 per peer)
+             dict(N=[254, 64, 508], params=dict(P1=1)), dict(N=[64, 254, 508], params=dict(P1=2), inv=1)]
     run_world(2, cases, tmp_path)
 
 
