@@ -33,6 +33,7 @@ void reg_pow2_f32() {
   reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
   reg_variant<float, 2048, 32, 32, 32, 2, 8, true>(3, 0);
   reg_variant<float, 4096, 32, 32, 32, 4, 4, true>(0);
+  reg_variant<float, 8192, 32, 32, 8, 32, 2, true>(0);   // long lines: correctness net, see the f64 comment
 }
 
 }  // namespace offtk

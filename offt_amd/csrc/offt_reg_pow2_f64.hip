@@ -23,6 +23,9 @@ void reg_pow2_f64() {
   reg_variant<double, 2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
   reg_variant<double, 2048, 32, 32, 32, 2, 4, true>(1, F_CC);
   reg_variant<double, 4096, 32, 32, 32, 4, 4, true>(0);
+  // 8192: one column per workgroup is all the LDS holds (64 KiB image + 32 KiB twiddles); strided sides then move
+  // 16-B segments -- a correctness net for long lines (the reference's FFTW takes them), not a tuned path
+  reg_variant<double, 8192, 32, 32, 8, 32, 1, true>(0);
 }
 
 }  // namespace offtk

@@ -273,6 +273,18 @@ def test_single_precision(built, n):
         assert rel(got.astype(np.complex128), want) <= TOL32
 
 
+@pytest.mark.parametrize("shape", [(8192, 4, 8), (4, 8192, 8), (8, 4, 8192)])
+def test_long_lines_8192(built, shape):
+    """8192-point lines (the longest register kernel; one column per workgroup in f64): every axis, both precisions"""
+    for layout in (dict(S=1), dict()):
+        got, _ = gpu_fft(shape, **layout)
+        want, _, _ = O.world_fft(*shape, 1, kind=1, **layout)
+        check64(got, want)
+    got, _ = gpu_fft(shape, precision=api.F32)
+    want, _, _ = O.world_fft(*shape, 1, kind=1)
+    assert rel(got.astype(np.complex128), want) <= TOL32
+
+
 @pytest.mark.parametrize("shape", [(2048, 8, 8), (8, 2048, 8), (8, 8, 2048)])
 def test_single_precision_2048_sides(built, shape):
     """BASELINE configs[4] kernels: a 2048-point single-precision pass on every axis, every output layout, against
@@ -345,7 +357,7 @@ def test_full_size_2048_single_precision_properties(built):
 def test_lengths_no_kernel_takes_are_refused_at_plan_time(built):
     """a line too long for every kernel (no register kernel, more than the any-length kernel's LDS) must fail in
     offt_3d_init, not on every execute (the reference's FFTW takes any N; this library says so up front)"""
-    for shape, prec in (((8, 8, 6000), api.F64), ((8192, 4, 4), api.F64), ((4, 12000, 4), api.F32)):
+    for shape, prec in (((8, 8, 6000), api.F64), ((16384, 4, 4), api.F64), ((4, 12000, 4), api.F32)):
         with pytest.raises(RuntimeError, match="offt_3d_init failed"):
             api.offt_3d_init(*shape, precision=prec)
     po = api.offt_3d_init(8, 8, 5000)   # 5000 = 2^3 5^4 fits the any-length kernel
@@ -507,6 +519,6 @@ def test_harness_and_static_sweep(built, tmp_path):
                                    stderr=subprocess.STDOUT).decode()
     assert len(open(db).read().splitlines()) == len(pts), out2
     # a run the library cannot do must FAIL: non-zero exit and the reference's t_min 999999999 line, not timings of
-    # an untransformed buffer (8192 points: no kernel takes the line)
-    p = subprocess.run([exe, "-N", "8192", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # an untransformed buffer (16384 points: no kernel takes the line)
+    p = subprocess.run([exe, "-N", "16384", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode != 0 and "t_min 999999999" in p.stdout.decode(), p.stdout.decode()
