@@ -388,6 +388,29 @@ def test_forced_tile_pipeline_on_one_gpu(built, monkeypatch):
         check64(got, want)
 
 
+def test_async_steps_and_wait(built, monkeypatch):
+    """offt_hip_set_async + offt_hip_wait: several transforms enqueued back to back (what bench.py times on several
+    ranks) give bit-identical results to the same number of synchronous calls -- direct path and tile pipelines"""
+    L = api.lib()
+    for env, shape, kw in ((None, (64, 64, 64), {}), ("1", (64, 32, 128), dict(T1=8, T2=8)), ("1", (64, 64, 32), dict(T1=16, T2=4, S=1))):
+        if env:
+            monkeypatch.setenv("OFFT_FORCE_PIPELINE", env)
+        else:
+            monkeypatch.delenv("OFFT_FORCE_PIPELINE", raising=False)
+        res = []
+        for asyn in (0, 1):
+            po = api.offt_3d_init(*shape, custom_params=api.make_params(**kw))
+            L.offt_hip_set_output_scale(po, 2.0 ** -9)
+            dev, _ = make_input(po, O.hash_field(*shape))
+            L.offt_hip_set_async(po, asyn)
+            for _ in range(3):
+                api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+            assert L.offt_hip_wait(po) == 0
+            res.append(dev.cpu().numpy().copy())
+            api.offt_3d_fin(po)
+        assert np.array_equal(res[0], res[1]), (shape, kw)
+
+
 def test_host_pointer_boundary(built):
     """the reference hands over a calloc'ed host array (run-fft.c:304): staged through HBM"""
     n = 32

@@ -74,7 +74,10 @@ def test_eight_ranks_one_gpu_bench_meshes(built, tmp_path):
              # the first-version exchange-volume layouts (kept for uneven grids) on an even grid
              dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
              dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=4), env=dict(OFFT_SLAB_XC_LAYOUT=1)),
-             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), inv=1)]
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), inv=1),
+             # row and column exchanges on two comm streams (OFFT_COMM_STREAMS=2): other event edges, same result
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), env=dict(OFFT_COMM_STREAMS=2)),
+             dict(N=[128, 128, 128], params=dict(P1=4, T1=8, T2=16, W2=0), env=dict(OFFT_COMM_STREAMS=2))]
     s = run_thread_world(8, cases, tmp_path)
     assert s[1]["mesh"] == [2, 4]  # offt-compute.c:3138-3139: the largest divisor of p that is <= sqrt(p)
 
