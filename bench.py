@@ -65,7 +65,7 @@ def _free_port():
     return port
 
 
-def launch(args, argv, script=None):
+def launch(args, argv, script=None, interpreter=sys.executable):
     import signal
     import tempfile
     n = args.gpus
@@ -79,7 +79,7 @@ def launch(args, argv, script=None):
         out = open(os.path.join(logdir, f"rank{r}.out"), "wb")
         err = open(os.path.join(logdir, f"rank{r}.err"), "wb")
         logs.append((out, err))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + argv, env=env, stdout=out, stderr=err,
+        procs.append(subprocess.Popen(([interpreter] if interpreter else []) + [os.path.abspath(script or __file__)] + argv, env=env, stdout=out, stderr=err,
                                       start_new_session=True))
 
     def tail(r, nbytes=3000):

@@ -52,6 +52,34 @@ int main(int argc, char **argv) {
   int is_oned = 0, is_a2a = 0, is_equalxy = 0, is_notest = 0, fft_alg = 0, verbose = 0, is_r2c = 0;
   int host_data = 0, gflops = 0, rc = 0;
   unsigned fftw_flag = FFTW_ESTIMATE;
+#ifndef OFFT_HARNESS_MPI
+  /* no MPI: a launcher (tools/launch.py, torchrun, srun ...) may still start one process per GPU and say so in the
+   * environment: RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them, plus OFFT_ID_FILE, a path on a file
+   * system all ranks see -- rank 0 writes the 128-byte RCCL id there, the others wait for it */
+  if (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1) {
+    p = atoi(getenv("WORLD_SIZE"));
+    rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+    const int dev = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
+    const char *idf = getenv("OFFT_ID_FILE");
+    char id[OFFT_HIP_UNIQUE_ID_BYTES];
+    if (!idf) { fprintf(stderr, "WORLD_SIZE > 1 needs OFFT_ID_FILE (or build the harness with MPI=1)\n"); return 2; }
+    if (rank == 0) {
+      char tmp[4096];
+      snprintf(tmp, sizeof tmp, "%s.tmp", idf);
+      if (offt_hip_get_unique_id(id)) return 2;
+      FILE *f = fopen(tmp, "wb");
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp); return 2; }
+      fclose(f);
+      if (rename(tmp, idf)) { fprintf(stderr, "cannot publish %s\n", idf); return 2; }
+    } else {
+      FILE *f = NULL;
+      for (int tries = 0; tries < 6000 && !(f = fopen(idf, "rb")); tries++) usleep(10000); /* up to 60 s */
+      if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no RCCL id in %s\n", rank, idf); return 2; }
+      fclose(f);
+    }
+    if (offt_hip_set_world(rank, p, id, dev)) return 3;
+  }
+#endif
 #ifdef OFFT_HARNESS_MPI
   MPI_Init(&argc, &argv);
   MPI_Comm_size(MPI_COMM_WORLD, &p);
@@ -140,6 +168,8 @@ int main(int argc, char **argv) {
     if (host_data) host_ramp(out, po->comm, is_r2c); else offt_hip_fill_input(po, out, 0);
 #ifdef OFFT_HARNESS_MPI
     MPI_Barrier(MPI_COMM_WORLD);
+#else
+    if (p > 1 && offt_hip_world_count() != p) { fprintf(stderr, "rank %d: not all %d ranks answered\n", rank, p); rc = 6; goto finish_plan; }
 #endif
     double t0 = now();
     offt_3d_execute(po, out, out, 0);
@@ -207,6 +237,8 @@ finish:
 #ifdef OFFT_HARNESS_MPI
   offt_hip_finalize_world();
   MPI_Finalize();
+#else
+  if (p > 1) offt_hip_finalize_world();
 #endif
   return rc;
 }

@@ -53,3 +53,20 @@ def test_under_an_external_launcher_no_ranks_are_spawned():
                                                                          MASTER_PORT="29631"))
     assert rc == 0, err
     assert json.loads(out.strip().splitlines()[-1])["n_ranks_seen"] == 1
+
+
+def test_generic_launcher_for_the_c_harness(tmp_path):
+    """tools/launch.py -n N -- <program>: the MPI-free `mpiexec -n N` for the C harness (RANK / LOCAL_RANK /
+    WORLD_SIZE / OFFT_ID_FILE in the environment); here with a script that just reports its environment"""
+    prog = tmp_path / "who.py"
+    prog.write_text("import os, sys\n"
+                    "print(os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], os.path.basename(os.environ['OFFT_ID_FILE']), sys.argv[1])\n"
+                    "sys.exit(4 if os.environ.get('FAIL_RANK') == os.environ['RANK'] else 0)\n")
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch.py"), "-n", "3", "--", str(prog), "hello"], env=e,
+                       capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout.decode().split() == ["0", "3", "0", "rccl_id", "hello"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch.py"), "-n", "3", "--", str(prog), "x"], env=dict(e, FAIL_RANK="2"),
+                       capture_output=True, timeout=120)
+    assert p.returncode != 0 and "rank 2 exited with code 4" in p.stderr.decode()

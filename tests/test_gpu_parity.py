@@ -6,6 +6,7 @@ single rel-L2 <= 5e-6."""
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -541,6 +542,10 @@ def test_harness_and_static_sweep(built, tmp_path):
     out2 = subprocess.check_output([exe, "-N", str(n), "-n", str(n), "-L", str(n), "-l", "4"], env=env,
                                    stderr=subprocess.STDOUT).decode()
     assert len(open(db).read().splitlines()) == len(pts), out2
+    # through the MPI-free launcher (one rank here: the box has one GPU): tools/launch.py -n 1 -- bin/run-fft ...
+    out3 = subprocess.check_output([sys.executable, os.path.join(root, "tools", "launch.py"), "-n", "1", "--", exe, "-N", "64", "-n", "64",
+                                    "-L", "64", "-v"], stderr=subprocess.STDOUT, timeout=300).decode()
+    assert any(l.startswith("p 0: 0 0 0: ") for l in out3.splitlines()), out3
     # a run the library cannot do must FAIL: non-zero exit and the reference's t_min 999999999 line, not timings of
     # an untransformed buffer (16384 points: no kernel takes the line)
     p = subprocess.run([exe, "-N", "16384", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

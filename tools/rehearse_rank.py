@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--layout", default="zyx")
+    ap.add_argument("--t1", type=int, default=-1, help="x-tile thickness (default: the library's)")
+    ap.add_argument("--t2", type=int, default=-1, help="z-chunk thickness (default: the library's)")
     args = ap.parse_args()
     os.environ.setdefault("OFFT_TEST_TRANSPORT_NOSYNC", "1")  # the no-op exchange needs no host synchronisation
     import torch
@@ -39,6 +41,10 @@ def main():
     params = dict(P1=args.p1)
     if args.layout == "xyz":
         params["S"] = 1
+    if args.t1 > 0:
+        params["T1"] = args.t1
+    if args.t2 > 0:
+        params["T2"] = args.t2
     n = args.n
     po = api.offt_3d_init(n, n, n, custom_params=api.make_params(**params), precision=prec)
     c = api.comm_dict(po)
