@@ -1417,14 +1417,15 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.ncols = c->m2; d.nb1 = myT;
         d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.out_axis_stride = c->M2; d.out_col_stride = 1; d.out_b1_stride = (long long)Tz * c->M2;
-        d.out_split = Tz; d.out_block_stride = (long long)c->M2 * Tz * T;
+        d.out_split = Tz; d.out_block_stride = (long long)c->M2 * Tz * T * nt; /* [peer][chunk][tile]: a (peer, chunk) run holds all tiles */
       } else {
         d.ncols = myT; d.nb1 = c->m2;
         d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1];
         d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
         if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
       }
-      if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, (char *)st->S1 + (size_t)i * p2 * st->sblkS * esz, s, 1)) return -1;
+      char *k1dst = (char *)st->S1 + (st->slab_yc ? (size_t)i * c->M2 * Tz * T : (size_t)i * p2 * st->sblkS) * esz;
+      if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, k1dst, s, 1)) return -1;
     }
     be->event_record(st->ev_s1[i], s);
   }
@@ -1439,7 +1440,10 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     for (int h = 0; h < H; h++) {
       const int z0 = h * Tz;
       int tz = c->M3 - z0; if (tz > Tz) tz = Tz;
-      const int groups = (h == 0) ? nt : 1, per = (h == 0) ? 1 : nt;
+      /* y-contiguous layout: the volume is [peer][chunk][tile], so chunk h > 0 is ONE contiguous message per peer (RCCL runs
+       * several operations to the same peer of one group one after the other: profiles/r02_overlap_trace_*_first.txt) */
+      const int merged = st->slab_yc && h > 0;
+      const int groups = (h == 0) ? nt : 1, per = (h == 0 || merged) ? 1 : nt;
       for (int g = 0; g < groups; g++) {
         const int cnt = per * p2;
         const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
@@ -1448,11 +1452,13 @@ static int execute_slab(struct _offt_plan *po, void *data) {
           const int i = (h == 0) ? g : ii;
           for (int a = 0; a < p2; a++) {
             const int e = ii * p2 + a;
-            const size_t off = (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
+            const size_t B = (size_t)c->M2 * Tz * T;
+            const size_t off = st->slab_yc ? ((((size_t)a * H + h) * nt + (merged ? 0 : i)) * B) * esz
+                                           : (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
             pr[e] = peers[a];
             sp[e] = (char *)st->S1 + off;
             rp[e] = (char *)st->R1 + off;
-            sb[e] = rb[e] = (size_t)tz * c->M2 * T * esz;
+            sb[e] = rb[e] = (merged ? (size_t)nt : (size_t)1) * tz * c->M2 * T * esz;
           }
         }
         if (run_a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
@@ -1468,8 +1474,8 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     if (st->x1) be->stream_wait(s, st->ev_sa[h]);
     /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
     if (nz > 0) {
-      const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (size_t)z0 * c->M2 * T * esz;
-      const size_t blk = st->sblkS;
+      const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (st->slab_yc ? (size_t)h * nt * c->M2 * Tz * T : (size_t)z0 * c->M2 * T) * esz;
+      const size_t blk = st->slab_yc ? st->sblkS * nt : st->sblkS;  /* peer block */
       for (int part = 0; part < 2; part++) { /* full tiles in one launch, the ragged tile in another */
         const int ntile = part == 0 ? nfull : (tail > 0 ? 1 : 0);
         if (!ntile) continue;
@@ -1477,7 +1483,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         offt_pass_desc d;
         desc_init(&d, st, po->Ny, -1, 1);
         d.ncols = part == 0 ? T : tail; d.nb1 = nz; d.nb2 = ntile;
-        d.in_b2_stride = (long long)p2 * blk;
+        d.in_b2_stride = st->slab_yc ? (long long)c->M2 * Tz * T : (long long)p2 * (long long)blk;  /* next tile */
         if (st->slab_yc) { /* whole y-lines (runs of F2 per peer block), columns = x_t */
           d.in_axis_stride = 1; d.in_contig = 1;
           d.in_col_stride = (long long)Tz * c->M2; d.in_b1_stride = c->M2;
@@ -1486,7 +1492,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         }
         if (p2 > 1) { d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0; d.in_block_stride = (long long)blk; }
         d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
-        if (run_pass(st, &d, src + (size_t)first * p2 * blk * esz,
+        if (run_pass(st, &d, src + (st->slab_yc ? (size_t)first * c->M2 * Tz * T : (size_t)first * p2 * blk) * esz,
                      (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s, 0)) return -1;
       }
     }
@@ -1614,12 +1620,12 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           d.in_block_stride = (long long)st->blk1;
         }
         d.out_axis_stride = T; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * T;
-        d.out_b2_stride = (long long)p1 * st->ntiles * B2;
+        d.out_b2_stride = (long long)B2; /* volume [peer][x-tile][z-chunk]: all chunks of a (peer, tile) are one contiguous message */
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
-          d.out_block_stride = (long long)st->ntiles * B2;
+          d.out_block_stride = (long long)st->ntiles * H * B2;
         }
-        if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * B2 * esz, s, 0)) return -1;
+        if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * H * B2 * esz, s, 0)) return -1;
       }
       for (int part = 0; part < 2 && myT > 0 && !st->pencil_yc; part++) {
         /* the chunks this rank fills completely go in one launch (chunk = second batch dimension), the ragged last
@@ -1653,7 +1659,8 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       if (st->x2) {
         be->stream_wait(st->s_comm2, st->ev_k2[r]);
         const int last = (k == st->ntiles - 1);
-        const int ngroups = last ? H : 1, per = last ? 1 : H;
+        const int merged = st->pencil_yc && !last; /* one contiguous message per peer holds every chunk of the tile */
+        const int ngroups = last ? H : 1, per = (last || merged) ? 1 : H;
         for (int g = 0; g < ngroups; g++) {
           const int cnt = per * p1;
           const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
@@ -1665,13 +1672,14 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
               const int e = hh * p1 + a;
               int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
               const size_t off = st->pencil_yc
-                                     ? (((size_t)h * p1 + a) * st->ntiles + k) * (size_t)Tz * c->M4 * T * esz
+                                     ? (((size_t)a * st->ntiles + k) * H + (merged ? 0 : h)) * (size_t)Tz * c->M4 * T * esz
                                      : ((size_t)a * st->blk2 + (size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz;
+              const size_t nch = merged ? (size_t)H : (size_t)1;
               pr[e] = peers2[a];
               sp[e] = (char *)st->send2 + off;
               rp[e] = (char *)st->recv2 + off;
-              sb[e] = (size_t)myT * c->M4 * tzh * esz;
-              rb[e] = (size_t)ma * c->M4 * tzh * esz;
+              sb[e] = nch * myT * c->M4 * tzh * esz;
+              rb[e] = nch * ma * c->M4 * tzh * esz;
               any |= (sb[e] || rb[e]);
             }
           }
@@ -1700,9 +1708,9 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const size_t B2 = (size_t)Tz * c->M4 * T;
       d.ncols = c->m4; d.nb1 = nz;
       d.in_axis_stride = 1; d.in_contig = 1; d.in_col_stride = T; d.in_b1_stride = (long long)c->M4 * T;
-      d.in_split = T; d.in_block_stride = (long long)B2;
+      d.in_split = T; d.in_block_stride = (long long)H * B2; /* (peer, tile) blocks are H chunks apart */
       d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2];
-      if (run_pass(st, &d, (char *)st->recv2 + (size_t)h * p1 * st->ntiles * B2 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
+      if (run_pass(st, &d, (char *)st->recv2 + (size_t)h * B2 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
       continue;
     }
     d.ncols = nz; d.nb1 = c->m4;
