@@ -727,9 +727,12 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->be = g_backend ? g_backend : &k_hip_backend;
   st->variant[0] = st->variant[1] = st->variant[2] = -1;
   st->out_scale = 1.0;
-  /* scratch planes are offset by an odd number of 128-B lines so that the 8 x-planes a
-   * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt) */
-  st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : 72;
+  /* scratch planes are offset by an odd number of 128-B lines (9 = 1152 B) so that the x-planes a
+   * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt).  In
+   * elements that is 72 for double and 144 for single precision: the 72 single-precision elements of r01
+   * put every odd plane 64 B off the lines, and the z pass's 128-B store segments straddled two of them
+   * (profiles/r02_wpad_f32.txt: 3-8 % on the z pass). */
+  st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : (precision == OFFT_HIP_F64 ? 72 : 144);
   /* ... and its y-lines can be given a pad too, so that the z pass's strided stores (one 128-B segment per line, lines
    * Ny elements apart) do not all fall on the same HBM channels when Ny * 16 B is a large power of two */
   st->wrow = getenv("OFFT_WROWPAD") ? atoi(getenv("OFFT_WROWPAD")) : 0;

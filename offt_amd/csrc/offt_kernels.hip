@@ -347,6 +347,7 @@ void build_registry() {
   reg_pow2_f64_anysplit();
   reg_pow2_f32();
   reg_pow2_f32_anysplit();
+  reg_pow2_f32_pair();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
   reg_mixed_f64_c();
@@ -364,7 +365,7 @@ std::mutex g_idx_mu;
 std::unordered_map<unsigned long long, std::vector<int>> g_idx;
 size_t g_idx_size = 0;
 unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c) {
-  return ((unsigned long long)n << 4) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
+  return ((unsigned long long)n << 8) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
 }
 
 Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false) {
@@ -743,14 +744,38 @@ void xcd_order(long long nblk, unsigned *lim, unsigned *gshift) {
   *lim = env > 0 ? (unsigned)((nblk >> (gs + 3)) << (gs + 3)) : 0u;
 }
 
+// Column-pair kernels (T = f32x2, offt_panel.hpp) take a descriptor with an even column count whose strided sides put the
+// two columns of a pair into 16 contiguous, 16-B aligned bytes: unit column stride, every other stride even (the base
+// pointers are checked at launch).  A contiguous side moves the two columns separately and needs nothing.
+bool pair_ok(const offt_pass_desc *d) {
+  if (d->precision != OFFT_PREC_F32 || d->real_input || (d->ncols & 1)) return false;
+  auto even = [](long long x) { return (x & 1) == 0; };
+  if (!d->in_contig && !(d->in_col_stride == 1 && even(d->in_axis_stride) && even(d->in_b1_stride) && even(d->in_b2_stride) &&
+                         even(d->in_block_stride)))
+    return false;
+  if (!d->out_contig && !(d->out_col_stride == 1 && even(d->out_axis_stride) && even(d->out_b1_stride) && even(d->out_b2_stride) &&
+                          even(d->out_block_stride)))
+    return false;
+  return true;
+}
+
 // the panel-kernel variant that will run this descriptor, or nullptr (-> any-length kernel)
-Variant *pick_variant(const offt_pass_desc *d) {
+Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
   if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return nullptr;
   const bool inc = d->in_contig != 0, outc = d->out_contig != 0, r2c = d->real_input != 0;
-  Variant *v = find_variant(d->n, d->precision, inc, outc, r2c ? -1 : d->variant, r2c);
-  if (!v) return nullptr;
   const bool uneven = d->in_split_nfloor > 0 || d->out_split_nfloor > 0;
   const bool odd_split = (d->in_split && !is_pow2(d->in_split)) || (d->out_split && !is_pow2(d->out_split));
+  static const bool pairs_on = !(getenv("OFFT_F32_PAIRS") && atoi(getenv("OFFT_F32_PAIRS")) == 0);
+  int want = d->variant;
+  if (want >= VARIANT_PAIR0 || (want < 0 && pairs_on)) {
+    if (allow_pair && !uneven && !odd_split && pair_ok(d)) {
+      Variant *p = find_variant(d->n, OFFT_PREC_F32_PAIR, inc, outc, want < 0 ? -1 : want - VARIANT_PAIR0);
+      if (p && (want >= 0 ? p->id == want - VARIANT_PAIR0 : p->is_default)) return p;
+    }
+    if (want >= VARIANT_PAIR0) want = -1;
+  }
+  Variant *v = find_variant(d->n, d->precision, inc, outc, r2c ? -1 : want, r2c);
+  if (!v) return nullptr;
   if (v->mixed || !(uneven || odd_split)) return v;
   // fft_panel_k addresses per-peer blocks with shifts: other block lengths go to the length's fft_panelx_k instance
   Variant *w = find_variant(d->n, d->precision, inc, outc, VARIANT_ANYSPLIT, r2c);
@@ -796,7 +821,7 @@ const char *offt_hipk_kernel_name(const offt_pass_desc *d) {
   const Variant *v = pick_variant(d);
   BlueTab bt;
   if (!v) return (!d->real_input && blue_lookup(d->n, d->precision, &bt) && find_blue(bt.m, d->precision, d->in_contig != 0, d->out_contig != 0)) ? "fft_bluestein_k" : "fft_mixed_k";
-  return v->mixed ? "fft_panelx_k" : "fft_panel_k";
+  return v->mixed ? "fft_panelx_k" : (v->prec == OFFT_PREC_F32_PAIR ? "fft_panel_k<pairs>" : "fft_panel_k");
 }
 
 int offt_hipk_prepare(int n, int precision) {
@@ -840,6 +865,9 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
   Variant *v = pick_variant(d);
+  if (v && v->prec == OFFT_PREC_F32_PAIR &&
+      ((!d->in_contig && ((uintptr_t)in & 15)) || (!d->out_contig && ((uintptr_t)out & 15))))
+    v = pick_variant(d, false);  // a strided side off the 16-B grid: the one-column kernels
   BlueTab bt;
   BlueVariant *bv = nullptr;
   if (!v && !d->real_input && blue_lookup(d->n, d->precision, &bt)) bv = find_blue(bt.m, d->precision, d->in_contig != 0, d->out_contig != 0);

@@ -44,6 +44,18 @@ template <> struct vec2<float> { using type = float2; };
 
 template <typename T> struct cx { T x, y; };
 
+// COLUMN PAIRS (single precision).  T = f32x2 runs the same kernel with two adjacent columns per lane: every register
+// value, butterfly operation and LDS word carries the pair (v_pk_* arithmetic, 8-B LDS words -- the double-precision
+// kernel's instruction count for twice the elements), a strided side moves 16 B per lane (one 128-B segment = 8 lanes, as in
+// double precision), twiddles and addresses are computed once per pair.  A contiguous side still moves 8 B per lane, one
+// access per column.  Needs an even column count and, on a strided side, a unit column stride with even other strides
+// (16-B alignment): pair_ok() in offt_kernels.hip; anything else runs on the one-column kernels.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <> struct vec2<f32x2> { using type = float2; };  // memory and twiddle tables hold plain complex floats
+template <typename T> struct lanes { using scalar = T; static constexpr int n = 1; };
+template <> struct lanes<f32x2> { using scalar = float; static constexpr int n = 2; };
+
 // global memory access helpers: 16-B (f64) / 8-B (f32) per lane.  Every element is
 // touched exactly once per pass, so loads and stores are non-temporal (streaming): A/B on
 // 1024^3 (profiles/r01_sweep.txt): -6 % transform time vs default cache policy.
@@ -75,6 +87,7 @@ __device__ __forceinline__ void gstore(V2 *p, V2 v) {
 // 32-bit XOR instead of a select + negate
 __device__ __forceinline__ double xor_sign(double v, unsigned m) { return __hiloint2double(__double2hiint(v) ^ (int)m, __double2loint(v)); }
 __device__ __forceinline__ float xor_sign(float v, unsigned m) { return __int_as_float(__float_as_int(v) ^ (int)m); }
+__device__ __forceinline__ f32x2 xor_sign(f32x2 v, unsigned m) { f32x2 r; r.x = xor_sign((float)v.x, m); r.y = xor_sign((float)v.y, m); return r; }
 
 // i / d for 0 <= i < 2^22 with inv = 1.0f / d: float estimate, one correction step each way
 __device__ __forceinline__ int fdiv(int i, int d, float inv) {
@@ -134,19 +147,20 @@ constexpr double WRS[33][32] = OFFT_WR_SIN;
 // d * w32^K, w32 = exp(-2 pi i / 32)
 template <typename T, int K>
 __device__ __forceinline__ cx<T> mulw32(cx<T> d) {
+  using S = typename lanes<T>::scalar;
   constexpr int k = K & 31;
   if constexpr (k == 0) return d;
   else if constexpr (k == 8) return cx<T>{d.y, -d.x};
   else if constexpr (k == 16) return cx<T>{-d.x, -d.y};
   else if constexpr (k == 24) return cx<T>{-d.y, d.x};
   else if constexpr (k == 4) {
-    constexpr T s = (T)W32C[4];
+    constexpr S s = (S)W32C[4];
     return cx<T>{(d.x + d.y) * s, (d.y - d.x) * s};
   } else if constexpr (k == 12) {
-    constexpr T s = (T)W32C[4];
+    constexpr S s = (S)W32C[4];
     return cx<T>{(d.y - d.x) * s, -(d.x + d.y) * s};
   } else {
-    constexpr T c = (T)W32C[k], s = (T)W32S[k];
+    constexpr S c = (S)W32C[k], s = (S)W32S[k];
     return cx<T>{d.x * c + d.y * s, d.y * c - d.x * s};
   }
 }
@@ -218,7 +232,7 @@ struct PanelCfg {
   //    only when it does not cost a workgroup per CU.
   static constexpr int QTQ = (N >= 4) ? N / 4 + 1 : 1, QTH = N / 2, T1N = NSTAGE > 1 ? R0 * (R1 - 1) : 0;
   static constexpr size_t lds_with(int shared_entries, int t1_entries) {
-    return NSTAGE > 1 ? TW_OFF + ((size_t)shared_entries + (size_t)t1_entries) * 2 * sizeof(T) : 0;
+    return NSTAGE > 1 ? TW_OFF + ((size_t)shared_entries + (size_t)t1_entries) * 2 * sizeof(typename lanes<T>::scalar) : 0;
   }
   static constexpr int wg_for(size_t lds) { return lds ? (int)(160 * 1024 / lds) : 8; }
 #ifdef OFFT_NO_OPT_TW
@@ -228,7 +242,7 @@ struct PanelCfg {
   static constexpr bool USE_HALF = NSTAGE > 1 && N >= 16 && wg_for(lds_with(QTH, USE_T1 ? T1N : 0)) == wg_for(lds_with(QTQ, 0));
 #endif
   static constexpr int QT = USE_HALF ? QTH : QTQ;
-  static constexpr size_t T1_OFF = TW_OFF + (size_t)QT * 2 * sizeof(T);
+  static constexpr size_t T1_OFF = TW_OFF + (size_t)QT * 2 * sizeof(typename lanes<T>::scalar);
   static constexpr size_t LDS_BYTES = lds_with(QT, USE_T1 ? T1N : 0);
   // occupancy target handed to __launch_bounds__ (2nd argument = waves per
   // SIMD): as many workgroups per CU as the 160 KiB LDS admits, at most 4
@@ -257,6 +271,10 @@ __global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, CO
 fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
             const typename vec2<T>::type *twq) {
   using V2 = typename vec2<T>::type;
+  using S = typename lanes<T>::scalar;
+  constexpr int NL = lanes<T>::n;   // memory columns per lane (2: column pairs)
+  constexpr bool PAIR = NL == 2;
+  using XV = std::conditional_t<PAIR, f32x4, V2>;  // packed exchange word: (re, im) of the lane's column(s)
   using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
   constexpr int TPL = Cfg::TPL, NT = Cfg::NT, NSTAGE = Cfg::NSTAGE;
   constexpr int LSTRIDE = Cfg::LSTRIDE;
@@ -264,10 +282,11 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   constexpr int PS = SWZ ? Cfg::SWZSHIFT : Cfg::PADSHIFT;
   static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
   static_assert(E % R0 == 0 && E % R1 == 0 && E % R2 == 0 && N % E == 0, "bad E");
+  static_assert(!(PAIR && R2C), "column pairs: complex input only");
 
   extern __shared__ __align__(16) unsigned char smem[];
   T *exs = reinterpret_cast<T *>(smem);
-  V2 *exv = reinterpret_cast<V2 *>(smem);
+  XV *exv = reinterpret_cast<XV *>(smem);
   V2 *tw = reinterpret_cast<V2 *>(smem + Cfg::TW_OFF);
   V2 *tw1 = reinterpret_cast<V2 *>(smem + Cfg::T1_OFF);
 
@@ -290,7 +309,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   const unsigned rest = bid / (unsigned)a.ncp;
   const int b1 = rest % (unsigned)a.nb1;
   const int b2 = rest / (unsigned)a.nb1;
-  const int c0 = cp * COLS;
+  const int c0 = cp * COLS * NL;
 #ifdef OFFT_NO_OPT_CONJ
   const unsigned conj_mask = 0u;
 #else
@@ -310,12 +329,16 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   if constexpr (INC) { j = tid % TPL; c = tid / TPL; }
   else               { c = tid % COLS; j = tid / COLS; }
   {
-    const bool valid = (c0 + c) < a.ncols;
-    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + c) * a.in_col;
+    const bool valid = (c0 + c * NL) < a.ncols;  // (pairs: the host sends even column counts only)
+    // pairs: lanes past the last column re-read the panel's first pair instead of being predicated off (a predicated
+    // load whose components are then regrouped into register pairs compiled to one branch and one full wait PER LOAD);
+    // what they compute is never stored
+    const int cl = (PAIR && !valid) ? 0 : c;
+    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + cl * NL) * a.in_col;
     const int mask = (int)((1u << a.in_shift) - 1u);
     auto load_all = [&](auto fast) {
       constexpr bool FAST = decltype(fast)::value;
-      const V2 *p0 = src + (FAST ? (long long)(j >> a.in_shift) * a.in_blk + (long long)(j & mask) * a.in_axis : 0LL);
+      const V2 *p0 = src + ((FAST || PAIR) ? (long long)(j >> a.in_shift) * a.in_blk + (long long)(j & mask) * a.in_axis : 0LL);
       static_for<0, E>([&](auto ii) {
         constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
         constexpr int cn = u * TPL + t * (N / R0);
@@ -324,8 +347,21 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         val.x = 0; val.y = 0;
         if constexpr (R2C) {
           // n real values at the head of the row: element n is the n-th T of the row
-          if (valid) val.x = reinterpret_cast<const T *>(src)[n];
-          v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+          if constexpr (!PAIR) {
+            if (valid) val.x = reinterpret_cast<const T *>(src)[n];
+            v[decltype(ii)::value] = cx<T>{val.x, (T)0};
+          }
+        } else if constexpr (PAIR) {
+          const long long off = (long long)(cn >> a.in_shift) * a.in_blk + (long long)(cn & mask) * a.in_axis;  // uniform
+          T re, im;
+          if constexpr (INC) {  // lanes along the line: one 8-B access per column
+            const V2 w0 = gload(p0 + off), w1 = gload(p0 + off + a.in_col);
+            re.x = w0.x; re.y = w1.x; im.x = w0.y; im.y = w1.y;
+          } else {              // lanes across columns: the pair is 16 contiguous bytes
+            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p0 + off));
+            re.x = q.x; im.x = q.y; re.y = q.z; im.y = q.w;
+          }
+          v[decltype(ii)::value] = cx<T>{re, xor_sign(im, conj_mask)};
         } else {
           if constexpr (FAST) {
             const long long off = (long long)(cn >> a.in_shift) * a.in_blk + (long long)(cn & mask) * a.in_axis;  // uniform
@@ -356,6 +392,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     constexpr int NB = E / R;           // butterflies per thread
     constexpr int LR = ilog2(R);
 
+#ifndef OFFT_ABL_NOTW  /* developer ablation builds (tools/dev_ablate.sh): results are wrong, timings tell what a part costs */
     if constexpr (s > 0) {
       // inter-stage twiddles w_N^(k * t * N/(Ns*R)), k = q mod Ns
       constexpr int M = N / (Ns * R);
@@ -370,7 +407,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         const int km = (q & (Ns - 1)) * M;
         static_for<1, R>([&](auto tt) {
           constexpr int t = decltype(tt)::value;
-          T cr, ci;
+          S cr, ci;
           if constexpr (s == 1 && Cfg::USE_T1) {
             const V2 w = tw1[(t - 1) * R0 + (q & (R0 - 1))];  // consecutive lanes, consecutive entries
             cr = w.x; ci = w.y;
@@ -384,7 +421,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
             const int qd = e / (N / 4);
             const int r = e & (N / 4 - 1);
             V2 w = tw[r];
-            T wr = w.x, wi = w.y;
+            S wr = w.x, wi = w.y;
             // multiply by (-i)^qd
             cr = (qd & 1) ? wi : wr;
             ci = (qd & 1) ? -wr : wi;
@@ -395,8 +432,11 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         });
       });
     }
+#endif
 
+#ifndef OFFT_ABL_NOBF
     static_for<0, NB>([&](auto uu) { dft_reg<T, R>(&v[decltype(uu)::value * R]); });
+#endif
 
     if constexpr (s < NSTAGE - 1) {
       // ---- exchange through LDS: write Stockham-ordered, read strided --------
@@ -436,6 +476,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         }
       };
       // previous exchange's reads done (its reader mapping is this exchange's writer mapping)
+#ifndef OFFT_ABL_NOEX
       if constexpr (s > 0) xsync(std::integral_constant<bool, PRIV_W>{});
       constexpr std::integral_constant<bool, PRIV> priv{};
       if constexpr (SPLIT) {
@@ -463,36 +504,54 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           cx<T> x = v[u * R + bitrev(t, LR)];
-          V2 w; w.x = x.x; w.y = x.y;
+          XV w;
+          if constexpr (PAIR) { w.x = x.x.x; w.y = x.x.y; w.z = x.y.x; w.w = x.y.y; }
+          else { w.x = x.x; w.y = x.y; }
           exv[wr_idx(u, t)] = w;
         });
         xsync(priv);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / Rn, t = decltype(ii)::value % Rn;
-          V2 w = exv[rd_idx(u, t)];
-          v[decltype(ii)::value] = cx<T>{w.x, w.y};
+          XV w = exv[rd_idx(u, t)];
+          if constexpr (PAIR) { T re = {w.x, w.y}, im = {w.z, w.w}; v[decltype(ii)::value] = cx<T>{re, im}; }
+          else v[decltype(ii)::value] = cx<T>{w.x, w.y};
         });
       }
+#endif
       c = cn; j = jn;
     } else {
       // ---------------- last stage: global store ------------------------------
-      const bool valid = (c0 + c) < a.ncols;
-      V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c) * a.out_col;
+      const bool valid = (c0 + c * NL) < a.ncols;
+      V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c * NL) * a.out_col;
       const int mask = (int)((1u << a.out_shift) - 1u);
-      const T sc = (T)a.scale;
+      const S sc = (S)a.scale;
 #ifdef OFFT_NO_OPT_CONJ
-      const T scy = sc;
+      const S scy = sc;
 #else
-      const T scy = a.conj ? -sc : sc;  // conj-out rides on the scale
+      const S scy = a.conj ? -sc : sc;  // conj-out rides on the scale
 #endif
       auto store_all = [&](auto fast) {
         constexpr bool FAST = decltype(fast)::value;
-        V2 *p0 = dst + (FAST ? (long long)(j >> a.out_shift) * a.out_blk + (long long)(j & mask) * a.out_axis : 0LL);
+        V2 *p0 = dst + ((FAST || PAIR) ? (long long)(j >> a.out_shift) * a.out_blk + (long long)(j & mask) * a.out_axis : 0LL);
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           constexpr int cn = u * TPL + t * (N / R);
           const int n = j + cn;
           cx<T> x = v[u * R + bitrev(t, LR)];
+          if constexpr (PAIR) {
+            const T wx = x.x * sc, wy = x.y * scy;
+            const long long off = (long long)(cn >> a.out_shift) * a.out_blk + (long long)(cn & mask) * a.out_axis;  // uniform
+            if constexpr (OUTC) {
+              V2 w0, w1;
+              w0.x = wx.x; w0.y = wy.x; w1.x = wx.y; w1.y = wy.y;
+              if (valid) gstore(p0 + off, w0);
+              if (valid) gstore(p0 + off + a.out_col, w1);
+            } else {
+              f32x4 q;
+              q.x = wx.x; q.y = wy.x; q.z = wx.y; q.w = wy.y;
+              if (valid) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(p0 + off));
+            }
+          } else {
           V2 w;
           w.x = x.x * sc;
 #ifdef OFFT_NO_OPT_CONJ
@@ -507,6 +566,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
             } else {
               gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
             }
+          }
           }
         });
       };
@@ -909,6 +969,25 @@ void reg_variant(int id, int defmask = -1) {
   if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
 }
 
+// column-pair instances of fft_panel_k (T = f32x2): kept under their own precision key so that the one-column variants and
+// their ids stay what they were; `defmask` says for which flavours an eligible descriptor prefers the pair kernel.
+enum { OFFT_PREC_F32_PAIR = 3, VARIANT_PAIR0 = 200 };  // descriptor variant 200 + id forces pair variant `id`
+template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
+void reg_variant_pair(int id, int defmask) {
+  using T = f32x2;
+  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
+  char nm[160];
+  snprintf(nm, sizeof nm, "f32 N=%d E=%d radix=%dx%dx%d cols=%d (column pairs) %s lds=%zuB", N, E, R0, R1, R2, 2 * COLS,
+           SPLIT ? "split-re/im" : "packed", (size_t)Cfg::LDS_BYTES);
+  auto add = [&](bool inc, bool outc, int bit, const void *fn) {
+    registry().push_back(Variant{N, OFFT_PREC_F32_PAIR, inc, outc, id, (defmask & bit) != 0, false, 2 * COLS, Cfg::NT, E, Cfg::LDS_BYTES, fn, nm, false, false, false, nullptr});
+  };
+  add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT>);
+  add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
+  add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
+  add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
+}
+
 // mixed-radix (2^a 3^b 5^c) panel kernel: TPL threads per line instead of elements per thread.
 // FLAV limits which (in_contig, out_contig) flavours are instantiated at all (compile time), defmask says for
 // which of them this variant is the default.
@@ -942,6 +1021,7 @@ void reg_pow2_f64_1024();
 void reg_pow2_f64_anysplit();
 void reg_pow2_f32();
 void reg_pow2_f32_anysplit();
+void reg_pow2_f32_pair();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();
 void reg_mixed_f64_c();

@@ -31,6 +31,33 @@ void reg_dev() {
   reg_variant<float, 2048, 32, 8, 16, 16, 16, true>(6, 0);
   reg_variant<float, 2048, 32, 16, 8, 16, 16, true>(7, 0);
 #endif
+#ifdef OFFT_DEV_ABL  /* round 2: ablation study (tools/dev_ablate.sh) on the product shapes of 256 / 1024 / 2048 */
+  reg_variant<double, 256, 16, 16, 16, 1, 8, false>(0);
+  reg_variant<double, 2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<double, 2048, 32, 32, 32, 2, 4, true>(1, F_CC);
+  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_SC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC | F_CS);
+  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
+#endif
+#ifdef OFFT_DEV_PAIR  /* round 2: single-precision column-pair kernels against the one-column product shapes */
+  reg_variant<float, 256, 16, 16, 16, 1, 16, false>(0);
+  reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_SC | F_CS);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 16, true>(0, F_SS | F_CS | F_SC);
+  reg_variant<float, 2048, 32, 32, 32, 2, 4, false>(2, F_CC);
+  reg_variant_pair<256, 16, 16, 16, 1, 8, false>(0, 0);
+  reg_variant_pair<512, 16, 16, 16, 2, 8, true>(0, 0);
+  reg_variant_pair<512, 32, 32, 16, 1, 8, true>(1, 0);
+  reg_variant_pair<1024, 32, 32, 32, 1, 8, true>(0, 0);
+  reg_variant_pair<1024, 16, 16, 16, 4, 8, true>(1, 0);
+  reg_variant_pair<2048, 16, 16, 16, 8, 8, true>(0, 0);
+  reg_variant_pair<2048, 32, 32, 32, 2, 4, true>(1, 0);
+  reg_variant_pair<2048, 32, 32, 32, 2, 8, true>(2, 0);
+#endif
 #ifdef OFFT_DEV_512
   reg_variant<double, 512, 16, 16, 16, 2, 8, true>(0, F_ALL);
   reg_variant<double, 512, 16, 16, 8, 4, 8, true>(1, 0);

@@ -19,10 +19,11 @@ void reg_pow2_f32() {
   // side keep 16 columns (128-B segments) and the split exchange.  profiles/r01_sweep.txt
   reg_variant<float, 512, 32, 32, 16, 1, 16, false>(0, F_SS | F_CS | F_SC);
   reg_variant<float, 512, 32, 32, 16, 1, 8, false>(1, F_CC);
-  // (re-measured with the XCD-aware panel order: the narrow packed panel now also wins contig-in/strided-out,
-  //  3.63 vs 4.12 ms on the z pass of 1024^3)
-  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_SC);
-  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC | F_CS);
+  // (r01 measured the narrow packed panel ahead on contig-in/strided-out as well, 3.63 vs 4.12 ms on the z pass of
+  //  1024^3 -- with the scratch planes 64 B off the 128-B lines (offt_host.c, wpad); on aligned planes the 16-column
+  //  panel's 128-B store segments win: 3.39-3.43 vs 3.73-3.76 ms, profiles/r02_wpad_f32.txt)
+  reg_variant<float, 1024, 32, 32, 32, 1, 16, true>(0, F_SS | F_SC | F_CS);
+  reg_variant<float, 1024, 32, 32, 32, 1, 8, false>(1, F_CC);
   // 2048 f32.  A strided side wants 16 columns (16 x 8 B = 128-B segments; the 8-column panel that used to be the
   // strided/strided default moved 64-B segments: 40 % of the roofline in the 8-rank rehearsal,
   // profiles/r02_rehearse_f32_2048_1x8_first.txt).  E=32 on 1024 threads (4 waves per SIMD, a few spilled registers) beats

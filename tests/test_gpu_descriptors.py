@@ -127,6 +127,95 @@ def test_random_descriptors(libs, n):
             assert np.abs(got - want).max() <= tol * scale * max(1.0, np.log2(n)), desc
 
 
+def make_pair_case(rng, n, variant):
+    """a single-precision descriptor the column-pair kernels accept: even column count; a strided side with unit column
+    stride and even other strides (the pair is 16 aligned bytes); a contiguous side with any strides; power-of-two
+    per-peer blocks or none"""
+    d = Desc()
+    d.n, d.precision = n, api.F32
+    d.direction = int(rng.choice([-1, -1, 1]))
+    d.ncols, d.nb1, d.nb2 = 2 * int(rng.integers(1, 30)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    d.in_contig, d.out_contig = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    d.variant, d.scale, d.real_input = variant, float(rng.choice([1.0, 0.5, 1.0 / n])), 0
+
+    def lay(contig):
+        split = int(rng.choice([0, 0, 2, 8, n // 4, n // 2]))
+        nblk, inner = (n // split, split) if split else (1, n)
+        if contig:
+            axis, col = 1, inner + int(rng.integers(0, 4))
+            plane = col * d.ncols
+            ev = 1
+        else:
+            col, axis = 1, d.ncols + 2 * int(rng.integers(0, 3))
+            plane = axis * inner
+            ev = 2
+        blk = plane + ev * int(rng.integers(0, 4))
+        b1 = blk * nblk + ev * int(rng.integers(0, 3))
+        b2 = b1 * d.nb1 + ev * int(rng.integers(0, 3))
+        return split, axis, col, b1, b2, (blk if split else 0), b2 * d.nb2 + 8
+    d.in_split, d.in_axis_stride, d.in_col_stride, d.in_b1_stride, d.in_b2_stride, d.in_block_stride, nin = lay(d.in_contig)
+    d.out_split, d.out_axis_stride, d.out_col_stride, d.out_b1_stride, d.out_b2_stride, d.out_block_stride, nout = lay(d.out_contig)
+    d.in_split_nfloor = d.out_split_nfloor = 0
+    return d, nin, nout
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_column_pair_kernels(libs, n):
+    """the single-precision column-pair kernels (T = f32x2: two adjacent columns per lane, 16 B per lane on a strided
+    side), every registered pair variant forced through descriptor variant 200 + id, against the CPU interpreter; plus
+    descriptors they must NOT take (odd column count, odd strides on a strided side, a base pointer off the 16-B grid),
+    which have to come out right on the one-column kernels"""
+    L, CB = libs
+    L.offt_hipk_kernel_name.restype = C.c_char_p
+    L.offt_hipk_kernel_name.argtypes = [C.POINTER(Desc)]
+    rng = np.random.default_rng(4200 + n)
+    assert L.offt_hipk_prepare(n, api.F32) == 0
+    ct = np.complex64
+
+    def check(d, nin, nout, shift=0):
+        src = (rng.standard_normal(nin + 1) + 1j * rng.standard_normal(nin + 1)).astype(ct)
+        want = np.full(nout + 1, 7 - 3j, dtype=ct)
+        assert CB.cpu_backend_run_pass(C.byref(d), src[shift:].ctypes.data_as(C.c_void_p), want[shift:].ctypes.data_as(C.c_void_p)) == 0
+        din = torch.from_numpy(src.view(np.float32).copy()).cuda()
+        dout = torch.from_numpy(np.full(nout + 1, 7 - 3j, dtype=ct).view(np.float32).copy()).cuda()
+        torch.cuda.synchronize()
+        rc = L.offt_hipk_fft_pass(C.byref(d), din.data_ptr() + 8 * shift, dout.data_ptr() + 8 * shift, None)
+        assert rc == 0, L.offt_hipk_last_error()
+        torch.cuda.synchronize()
+        got = dout.cpu().numpy().view(ct)
+        desc = {f: getattr(d, f) for f, _ in Desc._fields_}
+        assert np.abs(got - want).max() <= 5e-6 * np.abs(want).max() * np.log2(n), desc
+
+    seen = 0
+    for vid in range(4):
+        for _ in range(6):
+            d, nin, nout = make_pair_case(rng, n, 200 + vid)
+            name = L.offt_hipk_kernel_name(C.byref(d)).decode()
+            if name != "fft_panel_k<pairs>":
+                assert vid > 0, "no column-pair kernel registered for n=%d" % n
+                break
+            seen += 1
+            check(d, nin, nout)
+    assert seen >= 6
+    # not eligible: odd column count / an odd stride on a strided side / a misaligned base -> one-column kernels
+    for _ in range(6):
+        d, nin, nout = make_pair_case(rng, n, 200)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            d.ncols -= 1
+        elif kind == 1 and not d.in_contig:
+            d.in_b1_stride += 1
+            d.in_b2_stride += d.nb1
+            nin += d.nb1 * d.nb2 + 8
+        elif kind == 1 and not d.out_contig:
+            d.out_b1_stride += 1
+            d.out_b2_stride += d.nb1
+            nout += d.nb1 * d.nb2 + 8
+        if kind < 2 and (kind == 0 or not (d.in_contig and d.out_contig)):
+            assert L.offt_hipk_kernel_name(C.byref(d)).decode() == "fft_panel_k"
+        check(d, nin, nout, shift=1 if kind == 2 else 0)
+
+
 @pytest.mark.parametrize("n", [16, 64, 96, 100, 127, 256])
 def test_many_panels_xcd_order(libs, n):
     """grids of 300 .. 8000 panels with ragged last panels: the XCD-aware panel renumbering (panel_of_block) is a
