@@ -11,7 +11,7 @@ python3 - "$OUT" "$*" <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, re, sys
 out, what = sys.argv[1], sys.argv[2]
 def short(name):
-    m = re.search(r"(fft_panelx?_k)<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)", name)
+    m = re.search(r"(fft_panelx?_k)<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)", name)
     if m:
         k, t, N, E, r0, r1, r2, cols, inc, outc, split = m.groups()
         return f"{k}<{t},N={N},{'E' if k == 'fft_panel_k' else 'TPL'}={E},{r0}x{r1}x{r2},cols={cols},{'C' if inc == 'true' else 'S'}{'C' if outc == 'true' else 'S'},{'split' if split == 'true' else 'packed'}>"
