@@ -2,9 +2,10 @@
 # developer probe: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes) of one dev_perf.py run:  tools/dev_pmc_hbm.sh <N> [f64|f32]
 export TMPDIR=/tmp
 N=${1:-1000}; P=${2:-f64}
+MODE=zyx; [ "$P" = f32 ] && MODE=f32   # dev_perf.py: "zyx" = f64 z-y-x, "f32" = f32 z-y-x and x-y-z
 OUT=gpurun_out/pmc_hbm_$N; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -- python3 tools/dev_perf.py $N zyx > $OUT/f.log 2>&1 || { tail -5 $OUT/f.log; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 tools/dev_perf.py $N zyx > $OUT/w.log 2>&1 || { tail -5 $OUT/w.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -- python3 tools/dev_perf.py $N $MODE > $OUT/f.log 2>&1 || { tail -5 $OUT/f.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 tools/dev_perf.py $N $MODE > $OUT/w.log 2>&1 || { tail -5 $OUT/w.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 esz = 16 if "$P" == "f64" else 8

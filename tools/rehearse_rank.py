@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layout", default="zyx")
     ap.add_argument("--t1", type=int, default=-1, help="x-tile thickness (default: the library's)")
     ap.add_argument("--t2", type=int, default=-1, help="z-chunk thickness (default: the library's)")
+    ap.add_argument("--variants", default="", help="kernel variants vx,vy,vz (offt_hip_set_variant; 200 + id = column-pair variant id)")
     args = ap.parse_args()
     os.environ.setdefault("OFFT_TEST_TRANSPORT_NOSYNC", "1")  # the no-op exchange needs no host synchronisation
     import torch
@@ -48,6 +49,9 @@ def main():
     n = args.n
     po = api.offt_3d_init(n, n, n, custom_params=api.make_params(**params), precision=prec)
     c = api.comm_dict(po)
+    if args.variants:
+        for ax, vv in enumerate(int(x) for x in args.variants.split(",")):
+            L.offt_hip_set_variant(po, ax, vv)
     dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64 if prec == api.F64 else torch.float32, device="cuda")
     torch.cuda.synchronize()
     L.offt_hip_fill_input(po, dev.data_ptr(), 1)
@@ -62,7 +66,7 @@ def main():
             best = (tot, list(t))
     local = float(n) ** 3 / args.ranks
     v = list(po.contents.params.contents.v)
-    print(f"rehearsal {n}^3 {args.dtype} rank 0 of {args.ranks}, mesh {c['p1']}x{c['p2']}, T1 {v[1]} W1 {v[2]} T2 {v[12]}: kernels only "
+    print(f"rehearsal {n}^3 {args.dtype} rank 0 of {args.ranks}, mesh {c['p1']}x{c['p2']}, variants {args.variants or 'default'}, T1 {v[1]} W1 {v[2]} T2 {v[12]}: kernels only "
           f"{best[0]*1e3:.3f} ms per transform = {6*esz*local/best[0]/8e12*100:.1f} % of 8 TB/s on the rank's 6*S*E/P bytes "
           f"(phase 1 {best[1][0]*1e3:.3f} ms, last phase {best[1][2]*1e3:.3f} ms)", flush=True)
     api.offt_3d_fin(po)
