@@ -947,6 +947,20 @@ static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _of
     const int ny = offt_hipk_variant_count(po->Ny, st->prec), nz = offt_hipk_variant_count(po->Nz, st->prec);
     if (ny > nv) nv = ny;
     if (nz > nv) nv = nz;
+    /* point 0 = the registry defaults (a different shape per pass flavour, column pairs in single precision): a uniform
+     * variant has to BEAT them to be taken.  It is recorded under the reference's default Px1 / Py1, which name no
+     * kernel shape, so feeding that line back (-P/-p) selects the defaults again. */
+    if (points < po->max_loop) {
+      for (int ax = 0; ax < 3; ax++) st->variant[ax] = -1;
+      double perf;
+      if (!db_lookup(po->point_database_file, v, &perf)) {
+        perf = sweep_time_point(po, buf, 0);
+        db_append(po->point_database_file, v, perf);
+      }
+      printf("@ SWEEP %.5f ", perf); print_params(v);
+      best = perf;
+      points++;
+    }
     for (int var = 0; var < nv && points < po->max_loop; var++, points++) {
       int e = 0, cols = 0;
       if (offt_hipk_variant_info(po->Nx, st->prec, var, &e, &cols) < 0 &&
