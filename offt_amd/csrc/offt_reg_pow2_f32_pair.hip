@@ -14,7 +14,9 @@ void reg_pow2_f32_pair() {
   reg_variant_pair<2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
   reg_variant_pair<2048, 32, 32, 32, 2, 4, true>(1, F_CC);
   reg_variant_pair<2048, 32, 32, 32, 2, 8, true>(2, 0);
-  reg_variant_pair<4096, 32, 32, 32, 4, 4, true>(0, 0);
+  // 4096: the one-column kernel fits 4 columns (32-B segments on a strided side, 19 % of the roofline); 4 pairs move 64-B
+  // segments: 54 % (profiles/r02_pair_4096.txt)
+  reg_variant_pair<4096, 32, 32, 32, 4, 4, true>(0, F_ALL);
 }
 
 }  // namespace offtk
