@@ -47,6 +47,10 @@ typedef struct offt_pass_desc {
    * the input line holds n REAL values (unit stride, in_contig = 1, no split) at the
    * start of a row of n/2+1 complex slots; only output indices 0..n/2 are stored. */
   int real_input;
+  /* cache hint: 1 = the output is read again right away by the next launch (the x pass over the group of z-planes the
+   * y pass has just written): store with the default cache policy so that it stays in L2 / the memory-side Infinity
+   * Cache, instead of the streaming (non-temporal) stores every other pass uses */
+  int out_keep;
 } offt_pass_desc;
 
 /* Build device twiddle tables etc. for length n; call at plan time (allocates). */

@@ -402,6 +402,8 @@ typedef struct hip_state {
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
+  int yx_fused;        /* the last single-rank execute alternated its y and x launches over groups of z-planes */
+  void *s_aux, *ev_aux[4]; /* ... with the x launches on this second stream, ordered behind their y launch by these events */
   int wpad, wrow;      /* scratch volume W: extra elements per x-plane / per y-line (de-aliasing pads) */
   int async;
   int timed;            /* this call records timing events (synchronous call, or host-staged) */
@@ -684,6 +686,8 @@ static void state_free(hip_state *st) {
   be->event_destroy(st->ev0); be->event_destroy(st->ev1);
   for (int i = 0; i < 4; i++) be->event_destroy(st->evp[i]);
   if (st->own_stream) be->stream_destroy(st->s_compute);
+  if (st->s_aux) be->stream_destroy(st->s_aux);
+  for (int i = 0; i < 4; i++) if (st->ev_aux[i]) be->event_destroy(st->ev_aux[i]);
   if (st->s_comm2 != st->s_comm1) be->stream_destroy(st->s_comm2);
   be->stream_destroy(st->s_comm1);
   free(st);
@@ -1235,6 +1239,56 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   }
   d[2].scale = st->out_scale; /* last launch */
   for (int i = 0; i < 3; i++) st->pass_slot[i] = slot[i];
+  /* Forward z-y-x: the y pass writes out[z][y][x] plane by plane and the x pass transforms those planes in place, so
+   * the two ALTERNATE over groups of z-planes small enough for the 256 MiB memory-side Infinity Cache: y(group) stores
+   * with the default cache policy (out_keep), x(group) finds its input there instead of in HBM -- one of the six
+   * read/write sweeps of the transform never reaches HBM.  1024^3 f64: y + x 11.5 -> 10.5 ms
+   * (tools/dev_mall_probe.py, profiles/r02_mall_probe.txt).  OFFT_ZGROUP_MIB sets the group size (0: off). */
+  st->yx_fused = 0;
+  if (zyx && dir < 0) {
+    static int group_mib = -1, two_streams = -1;
+    if (group_mib < 0) group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
+    if (two_streams < 0) two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 1;
+    const double plane_mib = (double)Nx * (double)Ny * (double)st->esz / (1024.0 * 1024.0);
+    int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
+    if (ng >= 1) {
+      if (ng > Nz) ng = Nz;
+      /* x(group) runs on a second stream behind its y(group), so that y(next group) fills the CUs x(group)'s last
+       * workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
+      int aux = two_streams && ng < Nz;
+      if (aux && !st->s_aux) {
+        st->s_aux = be->stream_create();
+        for (int i = 0; i < 4; i++) st->ev_aux[i] = be->event_create();
+        if (!st->s_aux || !st->ev_aux[0] || !st->ev_aux[1] || !st->ev_aux[2] || !st->ev_aux[3]) aux = 0;
+      }
+      if (st->timed) be->event_record(st->evp[0], s);
+      if (be->pass(&d[0], src[0], dst[0], s)) return -1;
+      if (st->timed) be->event_record(st->evp[1], s);
+      int k = 0;
+      for (int z0 = 0; z0 < Nz; z0 += ng, k++) {
+        const int g = Nz - z0 < ng ? Nz - z0 : ng;
+        offt_pass_desc dy = d[1], dx = d[2];
+        dy.nb1 = g; dx.nb1 = g;
+        dy.out_keep = 1;
+        const char *sy = (const char *)src[1] + (size_t)z0 * (size_t)dy.in_b1_stride * st->esz;
+        char *oy = (char *)dst[1] + (size_t)z0 * (size_t)dy.out_b1_stride * st->esz;
+        char *px = (char *)dst[2] + (size_t)z0 * (size_t)dx.out_b1_stride * st->esz;
+        if (be->pass(&dy, sy, oy, s)) return -1;
+        if (aux) {
+          be->event_record(st->ev_aux[k & 3], s);
+          be->stream_wait(st->s_aux, st->ev_aux[k & 3]);
+        }
+        if (be->pass(&dx, px, px, aux ? st->s_aux : s)) return -1;
+      }
+      if (aux) { /* the compute stream ends behind the last x launch */
+        be->event_record(st->ev_aux[k & 3], st->s_aux);
+        be->stream_wait(s, st->ev_aux[k & 3]);
+      }
+      if (st->timed) { be->event_record(st->evp[2], s); be->event_record(st->evp[3], s); }
+      st->yx_fused = 1; /* evp[1] .. evp[2] spans both passes: split evenly when read */
+      return 0;
+    }
+  }
   /* per-pass timing events only when somebody will read them: in asynchronous mode the call returns before
    * the GPU has finished, and each record costs a barrier packet (~2 us) between launches -- 20 % of a
    * 128^3 transform */
@@ -1509,6 +1563,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         }
         if (p2 > 1) { d.in_split = c->F2; d.in_split_nfloor = c->b2 ? p2 - c->b2 : 0; d.in_block_stride = (long long)blk; }
         d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
+        d.out_keep = 1; /* K3(h) reads this chunk of R2 right away: keep it in the Infinity Cache (see execute_single) */
         if (run_pass(st, &d, src + (st->slab_yc ? (size_t)first * c->M2 * Tz * T : (size_t)first * p2 * blk) * esz,
                      (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s, 0)) return -1;
       }
@@ -1855,7 +1910,8 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     st->pass_s[0] = ph1; st->pass_s[1] = 0; st->pass_s[2] = cc;
     t[PACK1] = ph1; t[FFTx] = cc;
   } else {
-    const double tt[3] = {a, b, cc};
+    double tt[3] = {a, b, cc};
+    if (st->yx_fused) tt[1] = tt[2] = 0.5 * b; /* the y and x launches alternate (execute_single): their shared time, halved */
     for (int i = 0; i < 3; i++) st->pass_s[st->pass_slot[i]] = tt[i];
     t[FFTz] = st->pass_s[0]; t[FFTy1] = st->pass_s[1]; t[FFTx] = st->pass_s[2];
   }

@@ -364,21 +364,21 @@ void build_registry() {
 std::mutex g_idx_mu;
 std::unordered_map<unsigned long long, std::vector<int>> g_idx;
 size_t g_idx_size = 0;
-unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c) {
-  return ((unsigned long long)n << 8) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
+unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c, bool keep = false) {
+  return ((unsigned long long)n << 8) | (keep ? 32u : 0u) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
 }
 
-Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false) {
+Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false, bool keep = false) {
   std::call_once(g_reg_once, build_registry);
   std::lock_guard<std::mutex> lk(g_idx_mu);
   auto &reg = registry();
   if (g_idx_size != reg.size()) {
     g_idx.clear();
     for (size_t i = 0; i < reg.size(); ++i)
-      g_idx[variant_key(reg[i].n, reg[i].prec, reg[i].inc, reg[i].outc, reg[i].r2c)].push_back((int)i);
+      g_idx[variant_key(reg[i].n, reg[i].prec, reg[i].inc, reg[i].outc, reg[i].r2c, reg[i].keep)].push_back((int)i);
     g_idx_size = reg.size();
   }
-  auto it = g_idx.find(variant_key(n, prec, inc, outc, r2c));
+  auto it = g_idx.find(variant_key(n, prec, inc, outc, r2c, keep));
   if (it == g_idx.end()) return nullptr;
   Variant *def = nullptr;
   for (int i : it->second) {
@@ -760,7 +760,7 @@ bool pair_ok(const offt_pass_desc *d) {
 }
 
 // the panel-kernel variant that will run this descriptor, or nullptr (-> any-length kernel)
-Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
+Variant *pick_variant0(const offt_pass_desc *d, bool allow_pair) {
   if (d->real_input && (!d->in_contig || d->in_axis_stride != 1 || d->in_split || d->direction > 0)) return nullptr;
   const bool inc = d->in_contig != 0, outc = d->out_contig != 0, r2c = d->real_input != 0;
   const bool uneven = d->in_split_nfloor > 0 || d->out_split_nfloor > 0;
@@ -780,6 +780,17 @@ Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
   // fft_panel_k addresses per-peer blocks with shifts: other block lengths go to the length's fft_panelx_k instance
   Variant *w = find_variant(d->n, d->precision, inc, outc, VARIANT_ANYSPLIT, r2c);
   return (w && w->id == VARIANT_ANYSPLIT) ? w : nullptr;
+}
+
+// ... and its cache-keeping twin when the descriptor asks for one (out_keep) and one is registered
+Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
+  Variant *v = pick_variant0(d, allow_pair);
+  static const bool keep_on = !(getenv("OFFT_KEEP_STORES") && atoi(getenv("OFFT_KEEP_STORES")) == 0);
+  if (v && d->out_keep && keep_on && !v->mixed && !v->r2c) {
+    Variant *k = find_variant(v->n, v->prec, v->inc, v->outc, v->id, false, true);
+    if (k && k->keep && k->id == v->id) return k;
+  }
+  return v;
 }
 
 bool fast_ok(const offt_pass_desc *d) { return pick_variant(d) != nullptr; }

@@ -83,6 +83,12 @@ __device__ __forceinline__ void gstore(V2 *p, V2 v) {
 #endif
 }
 
+template <bool KEEP, typename V2>
+__device__ __forceinline__ void gstore_p(V2 *p, V2 v) {
+  if constexpr (KEEP) *p = v;
+  else gstore(p, v);
+}
+
 // v with its sign bit XORed by m (m = 0 or 0x80000000, uniform): conjugation and half-wave twiddle signs cost one
 // 32-bit XOR instead of a select + negate
 __device__ __forceinline__ double xor_sign(double v, unsigned m) { return __hiloint2double(__double2hiint(v) ^ (int)m, __double2loint(v)); }
@@ -266,7 +272,8 @@ __device__ __forceinline__ int padidx(int i) {
   else return i + (i >> SHIFT);
 }
 
-template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
+template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false,
+          bool KEEP = false /* stores with the default cache policy: the next launch re-reads the output (out_keep) */>
 __global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
 fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
             const typename vec2<T>::type *twq) {
@@ -544,12 +551,13 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
             if constexpr (OUTC) {
               V2 w0, w1;
               w0.x = wx.x; w0.y = wy.x; w1.x = wx.y; w1.y = wy.y;
-              if (valid) gstore(p0 + off, w0);
-              if (valid) gstore(p0 + off + a.out_col, w1);
+              if (valid) gstore_p<KEEP>(p0 + off, w0);
+              if (valid) gstore_p<KEEP>(p0 + off + a.out_col, w1);
             } else {
               f32x4 q;
               q.x = wx.x; q.y = wy.x; q.z = wx.y; q.w = wy.y;
-              if (valid) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(p0 + off));
+              if constexpr (KEEP) { if (valid) *reinterpret_cast<f32x4 *>(p0 + off) = q; }
+              else { if (valid) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(p0 + off)); }
             }
           } else {
           V2 w;
@@ -562,9 +570,9 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
           if (valid && (!R2C || n <= N / 2)) {
             if constexpr (FAST) {
               const long long off = (long long)(cn >> a.out_shift) * a.out_blk + (long long)(cn & mask) * a.out_axis;  // uniform
-              gstore(p0 + off, w);
+              gstore_p<KEEP>(p0 + off, w);
             } else {
-              gstore(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
+              gstore_p<KEEP>(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
             }
           }
           }
@@ -939,6 +947,7 @@ struct Variant {
   bool mixed;       // fft_panelx_k (any split length incl. uneven, quarter or full twiddle table)
   bool full_table;
   void *modfn;      // hipFunction_t of an instance compiled at plan time (hipRTC), launched instead of fn
+  bool keep = false;  // KEEP instantiation (offt_pass_desc::out_keep): default-policy stores
 };
 // id of the fft_panelx_k instance a power-of-two length keeps for per-peer splits fft_panel_k cannot address
 // (uneven, or not a power of two: grids split over 3, 6, ... ranks)
@@ -967,6 +976,11 @@ void reg_variant(int id, int defmask = -1) {
   // real-input z pass: only the contiguous-read flavours of the default variant need it
   if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
   if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
+  // cache-keeping stores (out_keep): the contig-in / strided-out default, i.e. the y pass of the z-y-x schedules
+  if (defmask & F_CS) {
+    add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, false, true>);
+    registry().back().keep = true;
+  }
 }
 
 // column-pair instances of fft_panel_k (T = f32x2): kept under their own precision key so that the one-column variants and
@@ -986,6 +1000,10 @@ void reg_variant_pair(int id, int defmask) {
   add(false, false, F_SS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT>);
   add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT>);
   add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
+  if (defmask & F_CS) {
+    add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, false, true>);
+    registry().back().keep = true;
+  }
 }
 
 // mixed-radix (2^a 3^b 5^c) panel kernel: TPL threads per line instead of elements per thread.

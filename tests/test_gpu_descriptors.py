@@ -26,7 +26,7 @@ class Desc(C.Structure):
                 ("in_split", C.c_int), ("in_split_nfloor", C.c_int), ("out_split", C.c_int), ("out_split_nfloor", C.c_int),
                 ("in_block_stride", C.c_longlong), ("out_block_stride", C.c_longlong),
                 ("in_contig", C.c_int), ("out_contig", C.c_int), ("variant", C.c_int), ("scale", C.c_double),
-                ("real_input", C.c_int)]
+                ("real_input", C.c_int), ("out_keep", C.c_int)]
 
 
 def layout(rng, n, ncols, nb1, nb2, split, nfloor, contig):
@@ -63,6 +63,7 @@ def make_case(rng, n, prec, big_grid=False):
     d.variant = -1
     d.scale = float(rng.choice([1.0, 0.5, 1.0 / n]))
     d.real_input = 0
+    d.out_keep = int(rng.integers(0, 2))  # cache-keeping stores where a twin kernel exists (contig-in / strided-out defaults)
 
     def pick_split():
         kind = rng.integers(0, 3)
@@ -137,6 +138,7 @@ def make_pair_case(rng, n, variant):
     d.ncols, d.nb1, d.nb2 = 2 * int(rng.integers(1, 30)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
     d.in_contig, d.out_contig = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     d.variant, d.scale, d.real_input = variant, float(rng.choice([1.0, 0.5, 1.0 / n])), 0
+    d.out_keep = int(rng.integers(0, 2))
 
     def lay(contig):
         split = int(rng.choice([0, 0, 2, 8, n // 4, n // 2]))
