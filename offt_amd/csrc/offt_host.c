@@ -979,7 +979,8 @@ static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _of
         db_append(po->point_database_file, v, perf);
       }
       printf("@ SWEEP %.5f ", perf); print_params(v);
-      if (perf < best) { best = perf; best_variant = var; memcpy(best_v, v, sizeof best_v); }
+      /* (2 % hysteresis: box noise must not trade the per-flavour defaults for a uniform variant) */
+      if (perf < 0.98 * best) { best = perf; best_variant = var; memcpy(best_v, v, sizeof best_v); }
     }
     for (int ax = 0; ax < 3; ax++) st->variant[ax] = best_variant;
     memcpy(v, best_v, sizeof best_v);
@@ -1242,13 +1243,17 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   /* Forward z-y-x: the y pass writes out[z][y][x] plane by plane and the x pass transforms those planes in place, so
    * the two ALTERNATE over groups of z-planes small enough for the 256 MiB memory-side Infinity Cache: y(group) stores
    * with the default cache policy (out_keep), x(group) finds its input there instead of in HBM -- one of the six
-   * read/write sweeps of the transform never reaches HBM.  1024^3 f64: y + x 11.5 -> 10.5 ms
-   * (tools/dev_mall_probe.py, profiles/r02_mall_probe.txt).  OFFT_ZGROUP_MIB sets the group size (0: off). */
+   * read/write sweeps of the transform is served by the cache.  1024^3 f64: y + x 11.5 -> 10.7 ms, the transform
+   * 17.3 -> 16.5 ms (tools/dev_mall_probe.py, profiles/r02_mall_probe.txt, r02_zgroup*.txt).  OFFT_ZGROUP_MIB sets
+   * the group size (0: off). */
   st->yx_fused = 0;
-  if (zyx && dir < 0) {
+  /* (lines of up to 1024 points: the 2048-point kernels fill a CU with one workgroup, a group launch of theirs ends in
+   * a long tail, and 2048^3 f32 came out 2 % slower -- profiles/r02_zgroup2.txt) */
+  if (zyx && dir < 0 && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024))) {
     static int group_mib = -1, two_streams = -1;
     if (group_mib < 0) group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
-    if (two_streams < 0) two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 1;
+    /* OFFT_ZGROUP_STREAMS=2: x launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
+    if (two_streams < 0) two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
     const double plane_mib = (double)Nx * (double)Ny * (double)st->esz / (1024.0 * 1024.0);
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
