@@ -14,6 +14,9 @@ from offt_amd import api
 from test_gpu_descriptors import Desc
 
 
+KEEP = [0]
+
+
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     groups = [int(x) for x in sys.argv[2:]] or [4, 8, 16, 32, 128]
@@ -31,7 +34,7 @@ def main():
         d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2 = N, api.F64, -1, N, G, 1
         d.in_axis_stride, d.in_col_stride, d.in_b1_stride, d.in_contig = 1, wx, wy, 1
         d.out_axis_stride, d.out_col_stride, d.out_b1_stride, d.out_contig = os1, os0, os2, 0
-        d.variant, d.scale = -1, 1.0 / N
+        d.variant, d.scale, d.out_keep = -1, 1.0 / N, KEEP[0]
         assert L.offt_hipk_fft_pass(C.byref(d), W.data_ptr() + 16 * z0 * wy, data.data_ptr() + 16 * z0 * os2, None) == 0
 
     def xpass(z0, G):
@@ -45,6 +48,27 @@ def main():
         p = data.data_ptr() + 16 * z0 * os2
         assert L.offt_hipk_fft_pass(C.byref(d), p, p, None) == 0
 
+    # out-of-place variant: y(g) -> ring slot R[g % 2] (kept stores), x(g): ring slot -> data
+    ring = {}
+
+    def ypass_ring(z0, G, slot, keep=1):
+        d = Desc()
+        d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2 = N, api.F64, -1, N, G, 1
+        d.in_axis_stride, d.in_col_stride, d.in_b1_stride, d.in_contig = 1, wx, wy, 1
+        d.out_axis_stride, d.out_col_stride, d.out_b1_stride, d.out_contig = os1, os0, os2, 0
+        d.variant, d.scale, d.out_keep = -1, 1.0 / N, keep
+        assert L.offt_hipk_fft_pass(C.byref(d), W.data_ptr() + 16 * z0 * wy, ring[G].data_ptr() + 16 * slot * G * os2, None) == 0
+
+    def xpass_ring(z0, G, slot):
+        d = Desc()
+        d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2 = N, api.F64, -1, N, G, 1
+        d.in_axis_stride = d.out_axis_stride = os0
+        d.in_col_stride = d.out_col_stride = os1
+        d.in_b1_stride = d.out_b1_stride = os2
+        d.in_contig = d.out_contig = 1
+        d.variant, d.scale = -1, 1.0 / N
+        assert L.offt_hipk_fft_pass(C.byref(d), ring[G].data_ptr() + 16 * slot * G * os2, data.data_ptr() + 16 * z0 * os2, None) == 0
+
     def timed(fn, reps=3):
         best = 1e9
         for _ in range(reps):
@@ -57,7 +81,9 @@ def main():
             best = min(best, e0.elapsed_time(e1))
         return best
 
+    KEEP[0] = 0
     t_all = timed(lambda: (ypass(0, N), xpass(0, N)))
+    KEEP[0] = 1
     print(f"{N}^3 f64  y(all); x(all): {t_all:.3f} ms", flush=True)
     for G in groups:
         def alt():
@@ -71,7 +97,20 @@ def main():
             for z0 in range(0, N, G):
                 xpass(z0, G)
         t2 = timed(seq)
-        print(f"  groups of {G:4d} planes ({G * N * N * 16 >> 20} MiB): alternating {t:.3f} ms, same launches pass after pass {t2:.3f} ms", flush=True)
+        ring[G] = torch.zeros(2 * G * N * N * 2, dtype=torch.float64, device="cuda")
+        def oop():
+            for k, z0 in enumerate(range(0, N, G)):
+                ypass_ring(z0, G, k & 1)
+                xpass_ring(z0, G, k & 1)
+        t3 = timed(oop)
+        def oop_nt():
+            for k, z0 in enumerate(range(0, N, G)):
+                ypass_ring(z0, G, k & 1, keep=0)
+                xpass_ring(z0, G, k & 1)
+        t4 = timed(oop_nt)
+        del ring[G]
+        print(f"  groups of {G:4d} planes ({G * N * N * 16 >> 20} MiB): alternating in place {t:.3f} ms, same launches pass after pass {t2:.3f} ms, "
+              f"through a 2-slot ring (x pass out of place) {t3:.3f} ms, ring with streaming y stores {t4:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":

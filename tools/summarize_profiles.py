@@ -22,11 +22,11 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"fft_panel_k<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+))?>", name)
+    m = re.search(r"fft_panel_k<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
     if m:
-        t, N, E, r0, r1, r2, cols, inc, outc, split, r2c = m.groups()
+        t, N, E, r0, r1, r2, cols, inc, outc, split, r2c, keep = m.groups()
         return (f"fft_panel_k<{t},N={N},E={E},radix={r0}x{r1}x{r2},cols={cols},in_contig={inc},out_contig={outc},"
-                f"split={split}{',real_in' if r2c == 'true' else ''}>")
+                f"split={split}{',real_in' if r2c == 'true' else ''}{',keep' if keep in ('true', '1') else ''}>")
     return re.sub(r"\(.*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))[:100]
 
 
@@ -47,19 +47,32 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
 # per-pass durations from the kernel trace: the three panel launches of one transform are
 # dispatched in the order z, y, x (two of them may be the same kernel symbol with different strides)
 PASS = ["z", "y", "x"]
+
+
+def passes_of(disp):
+    """pass of every fft_panel_k dispatch (sorted by start).  With the y and x launches alternating over groups of
+    z-planes (the default up to 1024-point lines) a transform is 1 z launch + G (y, x) pairs: the y launches are the
+    `keep` twin of the contig-in/strided-out kernel, the x launches the contig/contig kernel.  Without it: z, y, x."""
+    names = [short(r["Kernel_Name"]) for r in disp]
+    if any(",keep>" in n for n in names):
+        return ["y" if ",keep>" in n else ("x" if "out_contig=true" in n else "z") for n in names]
+    return [PASS[i % 3] for i in range(len(disp))]
+
+
 trace = {p: [] for p in PASS}
 for fn in newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     disp = [r for r in csv.DictReader(open(fn)) if "fft_panel_k" in r["Kernel_Name"]]
     disp.sort(key=lambda r: int(r["Start_Timestamp"]))
-    for i, r in enumerate(disp):
-        trace[PASS[i % 3]].append((short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for p, r in zip(passes_of(disp), disp):
+        trace[p].append((short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 with open(os.path.join(dst, f"{tag}_pass_durations.csv"), "w") as f:
     w = csv.writer(f)
-    w.writerow(["Pass", "Kernel", "Launches", "AverageNs", "MinNs", "MaxNs"])
+    w.writerow(["Pass", "Kernel", "Launches", "AverageNs", "MinNs", "MaxNs", "LaunchesPerTransform", "NsPerTransform"])
+    ntr = max(1, len(trace["z"]))
     for p in PASS:
         if trace[p]:
             d = [x[1] for x in trace[p]]
-            w.writerow([p, trace[p][0][0], len(d), sum(d) / len(d), min(d), max(d)])
+            w.writerow([p, trace[p][0][0], len(d), sum(d) / len(d), min(d), max(d), len(d) / ntr, sum(d) / ntr])
 
 pm = {}
 out_rows = []
@@ -67,9 +80,8 @@ for ctr in ("fetch", "write"):
     for fn in newest(os.path.join(src, f"pmc_{ctr}", "*", "*_counter_collection.csv")):
         disp = [r for r in csv.DictReader(open(fn)) if "fft_panel_k" in r["Kernel_Name"]]
         disp.sort(key=lambda r: int(r["Start_Timestamp"]))
-        for i, r in enumerate(disp):
+        for p, r in zip(passes_of(disp), disp):
             s = short(r["Kernel_Name"])
-            p = PASS[i % 3]
             out_rows.append([p, s, r["Dispatch_Id"], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],
                              r["Counter_Name"], r["Counter_Value"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
             pm.setdefault((p, s, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
