@@ -1250,10 +1250,9 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   /* (lines of up to 1024 points: the 2048-point kernels fill a CU with one workgroup, a group launch of theirs ends in
    * a long tail, and 2048^3 f32 came out 2 % slower -- profiles/r02_zgroup2.txt) */
   if (zyx && dir < 0 && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024))) {
-    static int group_mib = -1, two_streams = -1;
-    if (group_mib < 0) group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
+    const int group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
     /* OFFT_ZGROUP_STREAMS=2: x launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
-    if (two_streams < 0) two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
+    const int two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
     const double plane_mib = (double)Nx * (double)Ny * (double)st->esz / (1024.0 * 1024.0);
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {

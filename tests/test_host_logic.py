@@ -52,6 +52,27 @@ def test_single_rank_direct(cpu1, shape, layout):
             assert v[i] == dv[i], n
 
 
+@pytest.mark.parametrize("streams", ["1", "2"])
+def test_single_rank_zgroups(cpu1, monkeypatch, streams):
+    """forward z-y-x on one rank with the y and x launches alternating over groups of z-planes (execute_single): 1 MiB
+    groups = 16 planes of 64 x 64, i.e. groups of 16, 16 and 8 planes here; also the ragged r2c plane count, and the x
+    launches on a second stream"""
+    monkeypatch.setenv("OFFT_ZGROUP_MIB", "1")
+    monkeypatch.setenv("OFFT_ZGROUP_STREAMS", streams)
+    shape = (64, 64, 40)
+    c, v, buf = cpu_world.run_rank(*shape)
+    G = np.zeros(shape, dtype=np.complex128)
+    cpu_world.scatter_out(c, buf, G)
+    assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
+    c, v, buf, back = cpu_world.run_rank(*shape, roundtrip=True)
+    assert back is not None
+    shape = (64, 64, 38)  # r2c: 20 planes of the half spectrum
+    c, v, buf = cpu_world.run_rank(*shape, is_r2c=1)
+    G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
+    cpu_world.scatter_out(c, buf, G)
+    assert rel(G, np.fft.rfftn(O.hash_field(*shape).real)) < TOL
+
+
 def test_single_rank_forced_pipeline(cpu1, monkeypatch):
     monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
     for shape, kw in [((8, 8, 8), dict(T1=2, W1=1)), ((12, 6, 10), dict(T1=5, W1=2)), ((8, 8, 8), dict(T1=3, W1=0, S=1)),
