@@ -739,7 +739,10 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->wpad = getenv("OFFT_WPAD") ? atoi(getenv("OFFT_WPAD")) : (precision == OFFT_HIP_F64 ? 72 : 144);
   /* ... and its y-lines can be given a pad too, so that the z pass's strided stores (one 128-B segment per line, lines
    * Ny elements apart) do not all fall on the same HBM channels when Ny * 16 B is a large power of two */
-  st->wrow = getenv("OFFT_WROWPAD") ? atoi(getenv("OFFT_WROWPAD")) : 0;
+  /* (measured: +7 % on the z pass of 256 x 2048 x 2048 f64 -- a 32 KiB pitch --, nothing or a slight loss at 16 KiB,
+   * profiles/r02_wrowpad_ab.txt: on by default, as nine 128-B lines, from 32 KiB up) */
+  st->wrow = getenv("OFFT_WROWPAD") ? atoi(getenv("OFFT_WROWPAD"))
+                                    : (((size_t)Ny * st->esz >= 32768 && (Ny & (Ny - 1)) == 0) ? (int)(1152 / st->esz) : 0);
   const offt_backend *be = st->be;
   double tb0 = wall_seconds();
   if (!g_backend) {
