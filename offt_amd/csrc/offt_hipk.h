@@ -57,6 +57,8 @@ typedef struct offt_pass_desc {
 int offt_hipk_prepare(int n, int precision);
 /* Launch one pass on `stream` (a hipStream_t).  No allocation, no sync.        */
 int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void *stream);
+/* 1 if the pass, with out_keep set, runs on a kernel whose stores stay cached (otherwise out_keep is ignored)          */
+int offt_hipk_keeps_output(const offt_pass_desc *d);
 /* 1 if a register/LDS Stockham panel kernel exists for (n, precision): powers of two up to 4096
  * and the swept 2^a 3^b 5^c lengths; 0 if the pass will run on the any-length kernel.        */
 int offt_hipk_has_fast_path(int n, int precision);

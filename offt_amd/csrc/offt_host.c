@@ -1252,7 +1252,9 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   st->yx_fused = 0;
   /* (lines of up to 1024 points: the 2048-point kernels fill a CU with one workgroup, a group launch of theirs ends in
    * a long tail, and 2048^3 f32 came out 2 % slower -- profiles/r02_zgroup2.txt) */
-  if (zyx && dir < 0 && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024))) {
+  /* (... and only where the y pass has a kernel with cache-keeping stores: without them the groups are just more
+   * launches -- the mixed-radix lengths lost 3-6 %, profiles/r02_size_table_final2.txt) */
+  if (zyx && dir < 0 && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024 && (g_backend || offt_hipk_keeps_output(&d[1]))))) {
     const int group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
     /* OFFT_ZGROUP_STREAMS=2: x launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
     const int two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;

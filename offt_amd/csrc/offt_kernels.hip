@@ -795,6 +795,14 @@ Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
 
 bool fast_ok(const offt_pass_desc *d) { return pick_variant(d) != nullptr; }
 
+// 1 if the descriptor, with out_keep set, runs on a kernel whose stores stay cached (a KEEP twin exists for its shape)
+extern "C" int offt_hipk_keeps_output(const offt_pass_desc *d) {
+  offt_pass_desc k = *d;
+  k.out_keep = 1;
+  const Variant *v = pick_variant(&k);
+  return v && v->keep;
+}
+
 int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 }  // namespace
