@@ -378,6 +378,26 @@ def test_linearity_and_shift(built):
     assert rel(Fs, F * np.exp(-2j * np.pi * 3 * k / n)[None, None, :]) < TOL64
 
 
+@pytest.mark.parametrize("streams", ["1", "2"])
+def test_y_x_launches_alternating_over_small_plane_groups(built, monkeypatch, streams):
+    """the forward z-y-x schedule of one GPU with its y and x launches alternating over groups of z-planes
+    (execute_single; by default 256 MiB groups, here 1 MiB: one to four planes per group, ragged last groups, hundreds of
+    launch pairs), x launches on the same or on a second stream; double and single precision (column-pair kernels with
+    cache-keeping stores), complex and real input"""
+    monkeypatch.setenv("OFFT_ZGROUP_MIB", "1")
+    monkeypatch.setenv("OFFT_ZGROUP_STREAMS", streams)
+    for shape in ((256, 256, 131), (128, 128, 77), (512, 512, 5)):
+        got, _ = gpu_fft(shape)
+        check64(got, np.fft.fftn(O.hash_field(*shape)))
+    shape = (256, 256, 67)
+    got, _ = gpu_fft(shape, precision=api.F32)
+    want = np.fft.fftn(O.hash_field(*shape).astype(np.complex64).astype(np.complex128))
+    assert rel(got.astype(np.complex128), want) <= TOL32
+    shape = (256, 256, 90)
+    got, _ = gpu_fft(shape, is_r2c=1)
+    check64(got, np.fft.rfftn(O.hash_field(*shape).real))
+
+
 def test_forced_tile_pipeline_on_one_gpu(built, monkeypatch):
     """the multi-rank code path (tile ring, fused pack/unpack descriptors, streams/events) with p = 1"""
     monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
