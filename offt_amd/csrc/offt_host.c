@@ -1447,6 +1447,13 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   if (T > c->M1) T = c->M1;
   if (!st->t2_custom) {
     int z8 = (c->M3 + 7) / 8; if (Tz < z8) Tz = z8;
+    /* ... but no chunk of R2 larger than the Infinity Cache: K2(h) leaves its chunk there for K3(h) (out_keep).  Per-rank
+     * kernels of 2048^3 f32 on 8 ranks: 9.54 ms with 1 GiB chunks, 9.03 ms with 256 MiB ones; 1024^3 f64 has 256 MiB
+     * chunks either way (profiles/r02_rehearse_chunks.txt).  More chunks also means a finer exchange pipeline. */
+    const int chunk_mib = getenv("OFFT_SLAB_CHUNK_MIB") ? atoi(getenv("OFFT_SLAB_CHUNK_MIB")) : 256;
+    const double plane_mib = (double)c->M4 * (double)c->M1 * (double)st->esz / (1024.0 * 1024.0);
+    const int tzc = chunk_mib > 0 ? (int)((double)chunk_mib / plane_mib) : 0;
+    if (tzc >= 1 && Tz > tzc) { Tz = tzc; while (Tz > 1 && c->M3 % Tz) Tz--; }
     while (Tz < c->M3 && (size_t)T * c->M2 * Tz * st->esz < min_msg) Tz *= 2;
   }
   if (Tz > c->M3) Tz = c->M3;
