@@ -101,3 +101,46 @@ def test_mpi_harness_compiles_and_links(built, tmp_path):
     # without -d the harness must leave the mesh to the library (run-fft.c:290-293 only sizes the buffer with p1 = p)
     src = open(os.path.join(ROOT, "harness", "run-fft.c")).read()
     assert "p1 = cp->v[_P1_] = p;" not in src
+
+
+def test_kernel_routing_without_a_gpu(built):
+    """which kernel family a pass descriptor resolves to is host logic of the kernel library and needs no device:
+    single-precision column pairs only for descriptors they can take (even column count, 16-B pairs on a strided side),
+    cache-keeping twins only where one is registered (so that the host alternates y and x launches only there)"""
+    import ctypes as C
+    from test_gpu_descriptors import Desc
+    L = api.lib()
+    L.offt_hipk_kernel_name.restype = C.c_char_p
+    L.offt_hipk_kernel_name.argtypes = [C.POINTER(Desc)]
+    L.offt_hipk_keeps_output.argtypes = [C.POINTER(Desc)]
+
+    def desc(n, prec, ncols=64, in_contig=1, out_contig=0):
+        d = Desc()
+        d.n, d.precision, d.direction, d.ncols, d.nb1, d.nb2 = n, prec, -1, ncols, 4, 1
+        if in_contig:
+            d.in_axis_stride, d.in_col_stride = 1, n
+        else:
+            d.in_axis_stride, d.in_col_stride = ncols, 1
+        if out_contig:
+            d.out_axis_stride, d.out_col_stride = 1, n
+        else:
+            d.out_axis_stride, d.out_col_stride = ncols, 1
+        d.in_b1_stride = d.out_b1_stride = n * ncols
+        d.in_contig, d.out_contig, d.variant, d.scale = in_contig, out_contig, -1, 1.0
+        return d
+
+    name = lambda d: L.offt_hipk_kernel_name(C.byref(d)).decode()
+    for n in (512, 1024, 2048, 4096):
+        assert name(desc(n, api.F32)) == "fft_panel_k<pairs>"
+        assert name(desc(n, api.F32, ncols=63)) == "fft_panel_k"        # odd column count
+        assert name(desc(n, api.F64)) == "fft_panel_k"
+    d = desc(1024, api.F32, in_contig=0)
+    assert name(d) == "fft_panel_k<pairs>"
+    d.in_b1_stride += 1                                                     # a pair would straddle the 16-B grid
+    assert name(d) == "fft_panel_k"
+    assert name(desc(256, api.F32)) == "fft_panel_k"                        # no pair kernel registered at 256
+    assert name(desc(768, api.F64)) == "fft_panelx_k"
+    # cache-keeping twins: the power-of-two contig-in / strided-out defaults, nothing else
+    for n, prec, want in ((1024, api.F64, 1), (512, api.F64, 1), (1024, api.F32, 1), (2048, api.F32, 1), (768, api.F64, 0), (1016, api.F64, 0)):
+        assert L.offt_hipk_keeps_output(C.byref(desc(n, prec))) == want, (n, prec)
+    assert L.offt_hipk_keeps_output(C.byref(desc(1024, api.F64, out_contig=1))) == 0
