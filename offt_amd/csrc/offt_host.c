@@ -1254,16 +1254,19 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
    * a long tail, and 2048^3 f32 came out 2 % slower -- profiles/r02_zgroup2.txt) */
   /* (... and only where the y pass has a kernel with cache-keeping stores: without them the groups are just more
    * launches -- the mixed-radix lengths lost 3-6 %, profiles/r02_size_table_final2.txt) */
-  if (zyx && dir < 0 && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024 && (g_backend || offt_hipk_keeps_output(&d[1]))))) {
+  /* The inverse runs the same three steps backwards (x in place, y, z): there the x launch of a group is the producer
+   * and the y launch the consumer. */
+  const int ia = dir < 0 ? 1 : 0, ib = ia + 1; /* producer / consumer launch of the pair that shares z-planes of `data` */
+  if (zyx && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
     const int group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
-    /* OFFT_ZGROUP_STREAMS=2: x launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
+    /* OFFT_ZGROUP_STREAMS=2: consumer launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
     const int two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
     const double plane_mib = (double)Nx * (double)Ny * (double)st->esz / (1024.0 * 1024.0);
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
       if (ng > Nz) ng = Nz;
-      /* x(group) runs on a second stream behind its y(group), so that y(next group) fills the CUs x(group)'s last
-       * workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
+      /* the consumer of a group runs on a second stream behind its producer, so that the next group's producer fills the
+       * CUs its last workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
       int aux = two_streams && ng < Nz;
       if (aux && !st->s_aux) {
         st->s_aux = be->stream_create();
@@ -1271,30 +1274,39 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
         if (!st->s_aux || !st->ev_aux[0] || !st->ev_aux[1] || !st->ev_aux[2] || !st->ev_aux[3]) aux = 0;
       }
       if (st->timed) be->event_record(st->evp[0], s);
-      if (be->pass(&d[0], src[0], dst[0], s)) return -1;
-      if (st->timed) be->event_record(st->evp[1], s);
+      if (dir < 0) { /* forward: the z pass first */
+        if (be->pass(&d[0], src[0], dst[0], s)) return -1;
+        if (st->timed) be->event_record(st->evp[1], s);
+      }
       int k = 0;
       for (int z0 = 0; z0 < Nz; z0 += ng, k++) {
         const int g = Nz - z0 < ng ? Nz - z0 : ng;
-        offt_pass_desc dy = d[1], dx = d[2];
-        dy.nb1 = g; dx.nb1 = g;
-        dy.out_keep = 1;
-        const char *sy = (const char *)src[1] + (size_t)z0 * (size_t)dy.in_b1_stride * st->esz;
-        char *oy = (char *)dst[1] + (size_t)z0 * (size_t)dy.out_b1_stride * st->esz;
-        char *px = (char *)dst[2] + (size_t)z0 * (size_t)dx.out_b1_stride * st->esz;
-        if (be->pass(&dy, sy, oy, s)) return -1;
+        offt_pass_desc da = d[ia], db = d[ib];
+        da.nb1 = g; db.nb1 = g;
+        da.out_keep = 1;
+        const char *sa = (const char *)src[ia] + (size_t)z0 * (size_t)da.in_b1_stride * st->esz;
+        char *oa = (char *)dst[ia] + (size_t)z0 * (size_t)da.out_b1_stride * st->esz;
+        const char *sb = (const char *)src[ib] + (size_t)z0 * (size_t)db.in_b1_stride * st->esz;
+        char *ob = (char *)dst[ib] + (size_t)z0 * (size_t)db.out_b1_stride * st->esz;
+        if (be->pass(&da, sa, oa, s)) return -1;
         if (aux) {
           be->event_record(st->ev_aux[k & 3], s);
           be->stream_wait(st->s_aux, st->ev_aux[k & 3]);
         }
-        if (be->pass(&dx, px, px, aux ? st->s_aux : s)) return -1;
+        if (be->pass(&db, sb, ob, aux ? st->s_aux : s)) return -1;
       }
-      if (aux) { /* the compute stream ends behind the last x launch */
+      if (aux) { /* the compute stream goes on behind the last consumer launch */
         be->event_record(st->ev_aux[k & 3], st->s_aux);
         be->stream_wait(s, st->ev_aux[k & 3]);
       }
-      if (st->timed) { be->event_record(st->evp[2], s); be->event_record(st->evp[3], s); }
-      st->yx_fused = 1; /* evp[1] .. evp[2] spans both passes: split evenly when read */
+      if (dir < 0) {
+        if (st->timed) { be->event_record(st->evp[2], s); be->event_record(st->evp[3], s); }
+      } else { /* inverse: the z pass last */
+        if (st->timed) { be->event_record(st->evp[1], s); be->event_record(st->evp[2], s); }
+        if (be->pass(&d[2], src[2], dst[2], s)) return -1;
+        if (st->timed) be->event_record(st->evp[3], s);
+      }
+      st->yx_fused = dir < 0 ? 1 : 2; /* the events around the pair span both launches: split evenly when read */
       return 0;
     }
   }
@@ -1927,7 +1939,9 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     t[PACK1] = ph1; t[FFTx] = cc;
   } else {
     double tt[3] = {a, b, cc};
-    if (st->yx_fused) tt[1] = tt[2] = 0.5 * b; /* the y and x launches alternate (execute_single): their shared time, halved */
+    /* the y and x launches alternate (execute_single): their shared time, halved */
+    if (st->yx_fused == 1) tt[1] = tt[2] = 0.5 * b;
+    else if (st->yx_fused == 2) tt[0] = tt[1] = 0.5 * a;
     for (int i = 0; i < 3; i++) st->pass_s[st->pass_slot[i]] = tt[i];
     t[FFTz] = st->pass_s[0]; t[FFTy1] = st->pass_s[1]; t[FFTx] = st->pass_s[2];
   }

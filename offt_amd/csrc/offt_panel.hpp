@@ -976,9 +976,14 @@ void reg_variant(int id, int defmask = -1) {
   // real-input z pass: only the contiguous-read flavours of the default variant need it
   if (defmask & F_CC) add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, true>, true);
   if (defmask & F_CS) add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, true>, true);
-  // cache-keeping stores (out_keep): the contig-in / strided-out default, i.e. the y pass of the z-y-x schedules
+  // cache-keeping stores (out_keep): the contig-in / strided-out default, i.e. the y pass of the z-y-x schedules ...
   if (defmask & F_CS) {
     add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, false, true>);
+    registry().back().keep = true;
+  }
+  // ... and the contig / contig default: the x pass of the INVERSE z-y-x transform, whose planes the y pass re-reads
+  if (defmask & F_CC) {
+    add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, false, true>);
     registry().back().keep = true;
   }
 }
@@ -1002,6 +1007,10 @@ void reg_variant_pair(int id, int defmask) {
   add(false, true, F_SC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, true, SPLIT>);
   if (defmask & F_CS) {
     add(true, false, F_CS, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, false, SPLIT, false, true>);
+    registry().back().keep = true;
+  }
+  if (defmask & F_CC) {
+    add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, false, true>);
     registry().back().keep = true;
   }
 }

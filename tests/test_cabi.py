@@ -140,7 +140,9 @@ def test_kernel_routing_without_a_gpu(built):
     assert name(d) == "fft_panel_k"
     assert name(desc(256, api.F32)) == "fft_panel_k"                        # no pair kernel registered at 256
     assert name(desc(768, api.F64)) == "fft_panelx_k"
-    # cache-keeping twins: the power-of-two contig-in / strided-out defaults, nothing else
+    # cache-keeping twins: the power-of-two contig-in defaults (y pass of the forward, x pass of the inverse), nothing else
     for n, prec, want in ((1024, api.F64, 1), (512, api.F64, 1), (1024, api.F32, 1), (2048, api.F32, 1), (768, api.F64, 0), (1016, api.F64, 0)):
         assert L.offt_hipk_keeps_output(C.byref(desc(n, prec))) == want, (n, prec)
-    assert L.offt_hipk_keeps_output(C.byref(desc(1024, api.F64, out_contig=1))) == 0
+    assert L.offt_hipk_keeps_output(C.byref(desc(1024, api.F64, out_contig=1))) == 1
+    assert L.offt_hipk_keeps_output(C.byref(desc(1024, api.F64, in_contig=0, out_contig=1))) == 0
+    assert L.offt_hipk_keeps_output(C.byref(desc(1024, api.F64, in_contig=0, out_contig=0))) == 0
