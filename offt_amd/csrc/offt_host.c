@@ -402,7 +402,7 @@ typedef struct hip_state {
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
-  int yx_fused;        /* the last single-rank execute alternated its y and x launches over groups of z-planes */
+  int yx_fused;        /* the last single-rank execute alternated launches i and i+1 over groups of planes: i + 1 (0: none) */
   void *s_aux, *ev_aux[4]; /* ... with the x launches on this second stream, ordered behind their y launch by these events */
   int wpad, wrow;      /* scratch volume W: extra elements per x-plane / per y-line (de-aliasing pads) */
   int async;
@@ -1255,32 +1255,40 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   /* (... and only where the y pass has a kernel with cache-keeping stores: without them the groups are just more
    * launches -- the mixed-radix lengths lost 3-6 %, profiles/r02_size_table_final2.txt) */
   /* The inverse runs the same three steps backwards (x in place, y, z): there the x launch of a group is the producer
-   * and the y launch the consumer. */
-  const int ia = dir < 0 ? 1 : 0, ib = ia + 1; /* producer / consumer launch of the pair that shares z-planes of `data` */
-  if (zyx && (getenv("OFFT_ZGROUP_MIB") || (Nx <= 1024 && Ny <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
+   * and the y launch the consumer.  The other two layouts have such a pair as well: their z and y passes both work
+   * inside x-planes (x-y-z: both in place; y-z-x forward: z into the scratch volume, y in place there), so z(group of
+   * x-planes) keeps and y(group) re-reads. */
+  int ia = -1, cnt = 0;       /* producer launch (the consumer is the next one); planes the two share */
+  double plane_elems = 0.0;
+  int len_a = 0, len_b = 0;   /* their line lengths */
+  if (zyx) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
+  else if (S || dir < 0) { ia = 0; cnt = Nx; plane_elems = (double)Ny * Nz; len_a = Nzf; len_b = Ny; }
+  if (ia >= 0 && d[ia].nb1 == cnt && d[ia + 1].nb1 == cnt && !d[ia].real_input &&
+      (getenv("OFFT_ZGROUP_MIB") || (len_a <= 1024 && len_b <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
+    const int ib = ia + 1;
     const int group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
     /* OFFT_ZGROUP_STREAMS=2: consumer launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
     const int two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
-    const double plane_mib = (double)Nx * (double)Ny * (double)st->esz / (1024.0 * 1024.0);
+    const double plane_mib = plane_elems * (double)st->esz / (1024.0 * 1024.0);
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
-      if (ng > Nz) ng = Nz;
+      if (ng > cnt) ng = cnt;
       /* the consumer of a group runs on a second stream behind its producer, so that the next group's producer fills the
        * CUs its last workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
-      int aux = two_streams && ng < Nz;
+      int aux = two_streams && ng < cnt;
       if (aux && !st->s_aux) {
         st->s_aux = be->stream_create();
         for (int i = 0; i < 4; i++) st->ev_aux[i] = be->event_create();
         if (!st->s_aux || !st->ev_aux[0] || !st->ev_aux[1] || !st->ev_aux[2] || !st->ev_aux[3]) aux = 0;
       }
-      if (st->timed) be->event_record(st->evp[0], s);
-      if (dir < 0) { /* forward: the z pass first */
-        if (be->pass(&d[0], src[0], dst[0], s)) return -1;
-        if (st->timed) be->event_record(st->evp[1], s);
+      for (int i = 0; i < ia; i++) { /* the launch ahead of the pair */
+        if (st->timed) be->event_record(st->evp[i], s);
+        if (be->pass(&d[i], src[i], dst[i], s)) return -1;
       }
+      if (st->timed) be->event_record(st->evp[ia], s);
       int k = 0;
-      for (int z0 = 0; z0 < Nz; z0 += ng, k++) {
-        const int g = Nz - z0 < ng ? Nz - z0 : ng;
+      for (int z0 = 0; z0 < cnt; z0 += ng, k++) {
+        const int g = cnt - z0 < ng ? cnt - z0 : ng;
         offt_pass_desc da = d[ia], db = d[ib];
         da.nb1 = g; db.nb1 = g;
         da.out_keep = 1;
@@ -1299,14 +1307,14 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
         be->event_record(st->ev_aux[k & 3], st->s_aux);
         be->stream_wait(s, st->ev_aux[k & 3]);
       }
-      if (dir < 0) {
-        if (st->timed) { be->event_record(st->evp[2], s); be->event_record(st->evp[3], s); }
-      } else { /* inverse: the z pass last */
-        if (st->timed) { be->event_record(st->evp[1], s); be->event_record(st->evp[2], s); }
-        if (be->pass(&d[2], src[2], dst[2], s)) return -1;
-        if (st->timed) be->event_record(st->evp[3], s);
+      /* (the events around the pair span both launches; the boundary inside it is recorded at its end: the reader
+       *  splits the pair's time evenly) */
+      if (st->timed) { be->event_record(st->evp[ib], s); be->event_record(st->evp[ib + 1], s); }
+      for (int i = ib + 1; i < 3; i++) { /* the launch behind the pair */
+        if (be->pass(&d[i], src[i], dst[i], s)) return -1;
+        if (st->timed) be->event_record(st->evp[i + 1], s);
       }
-      st->yx_fused = dir < 0 ? 1 : 2; /* the events around the pair span both launches: split evenly when read */
+      st->yx_fused = ia + 1;
       return 0;
     }
   }
@@ -1940,8 +1948,7 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
   } else {
     double tt[3] = {a, b, cc};
     /* the y and x launches alternate (execute_single): their shared time, halved */
-    if (st->yx_fused == 1) tt[1] = tt[2] = 0.5 * b;
-    else if (st->yx_fused == 2) tt[0] = tt[1] = 0.5 * a;
+    if (st->yx_fused) { const int i0 = st->yx_fused - 1; const double pr = tt[i0] + tt[i0 + 1]; tt[i0] = tt[i0 + 1] = 0.5 * pr; }
     for (int i = 0; i < 3; i++) st->pass_s[st->pass_slot[i]] = tt[i];
     t[FFTz] = st->pass_s[0]; t[FFTy1] = st->pass_s[1]; t[FFTx] = st->pass_s[2];
   }

@@ -64,8 +64,19 @@ def test_single_rank_zgroups(cpu1, monkeypatch, streams):
     G = np.zeros(shape, dtype=np.complex128)
     cpu_world.scatter_out(c, buf, G)
     assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
-    c, v, buf, back = cpu_world.run_rank(*shape, roundtrip=True)
-    assert back is not None
+    def roundtrip_ok(**kw):  # forward, then the inverse on the result: the input block times Nx Ny Nz
+        c, v, buf, back = cpu_world.run_rank(*shape, roundtrip=True, **kw)
+        s0, s1, s2 = c["istride"]
+        idx = (np.arange(shape[0])[:, None, None] * s0 + np.arange(shape[1])[None, :, None] * s1 + np.arange(shape[2])[None, None, :] * s2).ravel()
+        assert rel(back[idx].reshape(shape) / np.prod(shape), O.hash_field(*shape)) < TOL
+    roundtrip_ok()
+    # the other layouts alternate their z and y launches over groups of x-planes (25, 25 and 14 planes here)
+    for kw in (dict(S=1), dict(is_equalxy=1)):
+        c, v, buf = cpu_world.run_rank(*shape, **kw)
+        G = np.zeros(shape, dtype=np.complex128)
+        cpu_world.scatter_out(c, buf, G)
+        assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
+        roundtrip_ok(**kw)
     shape = (64, 64, 38)  # r2c: 20 planes of the half spectrum
     c, v, buf = cpu_world.run_rank(*shape, is_r2c=1)
     G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
