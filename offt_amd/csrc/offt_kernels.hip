@@ -346,6 +346,7 @@ void build_registry() {
   reg_pow2_f64_1024();
   reg_pow2_f64_anysplit();
   reg_pow2_f32();
+  reg_pow2_f32_big();
   reg_pow2_f32_anysplit();
   reg_pow2_f32_pair();
   reg_mixed_f64_a();

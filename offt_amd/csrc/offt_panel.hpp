@@ -1047,6 +1047,7 @@ void reg_pow2_f64();
 void reg_pow2_f64_1024();
 void reg_pow2_f64_anysplit();
 void reg_pow2_f32();
+void reg_pow2_f32_big();
 void reg_pow2_f32_anysplit();
 void reg_pow2_f32_pair();
 void reg_mixed_f64_a();
