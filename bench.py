@@ -14,12 +14,15 @@ wall-clock limit, kills the others when one fails, relays rank 0's line and exit
 failing rank's tail otherwise.  Ranks synchronise themselves (barrier before and after the timed
 steps, max over ranks; run-fft.c:309, 371-414).
 
-A "step" is one offt_3d_execute of the whole grid.  flops = 5 E log2 E, algorithmic bytes =
-6 * S * E / P per GPU per transform (S = 16 B double-complex, 8 B single-complex).
-Rank 0 prints ONE JSON line.  For N > 1 the headline is the 1 x N mesh (one exchange over all
-N - 1 xGMI links); the same line also carries the reference-default mesh (2 x 4 at N = 8), an
-exchange-only and a compute-only time of the headline schedule, the per-link rate against 153 GB/s,
-an xGMI link probe and the number of ranks that answered an all-reduce.
+A "step" is one synchronous offt_3d_execute of the whole grid, at every N (the reference harness
+times one call per repetition between barriers, run-fft.c:374-395).  flops = 5 E log2 E,
+algorithmic bytes = 6 * S * E / P per GPU per transform (S = 16 B double-complex, 8 B
+single-complex).  Rank 0 prints ONE JSON line.  For N > 1 the headline is the 1 x N
+mesh (one exchange over all N - 1 xGMI links) in that same synchronous mode; the line also carries
+the pipelined figure (`ms_per_step_pipelined`: the K steps enqueued back to back, one wait), the
+reference-default mesh (2 x 4 at N = 8), an exchange-only and a compute-only time of the headline
+schedule, the per-link rate against 153 GB/s, an xGMI link probe and the number of ranks that
+answered an all-reduce.
 """
 import argparse
 import json
@@ -206,6 +209,59 @@ def mem_available_gib():
 
 
 # ------------------------------------------------------------------------------------------------
+# the JSON line's derived blocks: pure functions of the measurements (tests/test_bench_launcher.py checks the keys on CPU)
+# ------------------------------------------------------------------------------------------------
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def roofline_block(pass_s, paired, multi, esz, E, world, dt_step, dev_s, traffic_lookup=None):
+    """roofline of the dominant kernel.  pass_s = device seconds of the z, y, x passes of one transform (events on the
+    plan's stream); `paired` = the y and x launches alternate over groups of planes, so only their SUM was measured."""
+    names = ["z", "y", "x"]
+    alg_launch = 2.0 * esz * E / world
+    if multi:
+        # multi-rank slab schedule: phase 0 = the FFTz launches (K1, all x-tiles, no waiting on the exchange);
+        # phase 2 = z-chunks of exchange-wait + FFTy + FFTx, which includes time on the wire
+        k, kdur, kname = 0, pass_s[0], "fft_panel_k (z-axis pass K1, all x-tiles)"
+        pass_ms = {"K1 (FFTz + pack, all x-tiles)": round(pass_s[0] * 1e3, 4),
+                   "exchange-wait + K2 + K3 (z-chunks)": round(pass_s[2] * 1e3, 4)}
+    elif paired:
+        # the pair's launches interleave: each of the two moves 2*S*E bytes, the slower one is not known separately, so the
+        # pair enters with HALF its time per launch-equivalent -- the z pass, a single launch, is named when it is slower
+        pair = pass_s[1] + pass_s[2]
+        if pass_s[0] >= 0.5 * pair:
+            k, kdur, kname = 0, pass_s[0], "fft_panel_k (z-axis pass)"
+        else:
+            k, kdur, kname = 1, 0.5 * pair, "fft_panel_k (y- and x-axis passes, alternating launches: half of the pair's time)"
+        pass_ms = {"z": round(pass_s[0] * 1e3, 4), "y+x (alternating launches, measured as a pair)": round(pair * 1e3, 4)}
+    else:
+        k = max(range(3), key=lambda i: pass_s[i])
+        kdur, kname = pass_s[k], f"fft_panel_k ({names[k]}-axis pass)"
+        pass_ms = {names[i]: round(pass_s[i] * 1e3, 4) for i in range(3)}
+    traffic = traffic_lookup(names[k]) if traffic_lookup else None
+    roof = {"bound": "hbm", "kernel": kname, "achieved": round(alg_launch / kdur / 1e9, 1) if kdur > 0 else None,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg_launch / kdur / HBM_PEAK, 4) if kdur > 0 else None,
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json (recorded with rocprofv3 --pmc in separate passes, NOT measured in this run)"
+                               if traffic is not None else None),
+            "avg_launch_ms": round(kdur * 1e3, 4), "alg_bytes_per_launch": alg_launch, "pass_ms": pass_ms,
+            "transform_frac": round(6.0 * esz * E / world / dt_step / HBM_PEAK, 4),
+            "transform_device_ms": round(dev_s * 1e3, 4)}
+    return roof
+
+
+def xgmi_block(group, esz, E, world, t_exchange_step):
+    """per-link rate of an exchange inside a group of `group` ranks (None for a group of one: nothing leaves the GPU)"""
+    if group <= 1 or t_exchange_step <= 0:
+        return None
+    link_bytes = esz * E / world / group  # per link and direction: (1/g) of the local volume to each of g-1 peers
+    return {"group": group, "links_used": group - 1, "bytes_per_link_per_direction": link_bytes,
+            "achieved_GBps_per_link_per_direction": round(link_bytes / t_exchange_step / 1e9, 2),
+            "link_peak_GBps_bidirectional": XGMI_LINK / 1e9,
+            "frac_of_link_bidirectional": round(2 * link_bytes / t_exchange_step / XGMI_LINK, 4)}
+
+
+# ------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------
 def rank_main(args):
@@ -326,38 +382,22 @@ def rank_main(args):
     p1_head = args.p1 if args.p1 > 0 else 1
     po, data = make_plan(p1_head)
     c = api.comm_dict(po)
-    dt, pass_s, dev_s = timed(po, data, args.steps, args.warmup, enqueue_only=multi)
+    # the SAME mode at every N: one synchronous offt_3d_execute per step between two barriers (run-fft.c:374-395)
+    dt, pass_s, dev_s = timed(po, data, args.steps, args.warmup, enqueue_only=False)
     steps = args.steps
     ms = dt / steps * 1e3
     value = flops * steps / dt / 1e9
     alg_bytes_transform = 6.0 * esz * E / world
-    names = ["z", "y", "x"]
-    if not multi:
-        # dominant kernel = the slowest of the three panel-FFT launches of one transform; one launch
-        # reads and writes every local element once: 2 * S * E / P algorithmic bytes
-        k = max(range(3), key=lambda i: pass_s[i])
-        kdur = pass_s[k]
-        kname = f"fft_panel_k ({names[k]}-axis pass)"
-    else:
-        # multi-rank slab schedule: phase 0 = the FFTz launches (K1, all x-tiles, no waiting on the
-        # exchange); phase 2 = z-chunks of exchange-wait + FFTy + FFTx, which includes time on the wire
-        k = 0
-        kdur = pass_s[0]
-        kname = "fft_panel_k (z-axis pass K1, all x-tiles)"
-    alg_launch = 2.0 * esz * E / world
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tj) and world == 1 and n == 1024 and prec == api.F64 and not multi:
+    paired = bool(L.offt_hip_last_passes_paired(po))
+
+    def traffic_lookup(axis):
+        if not (os.path.exists(TRAFFIC_JSON) and world == 1 and n == 1024 and prec == api.F64 and not multi):
+            return None
         try:
-            traffic = json.load(open(tj)).get(names[k] + "_pass_hbm_bytes_per_launch")
+            return json.load(open(TRAFFIC_JSON)).get(axis + "_pass_hbm_bytes_per_launch")
         except Exception:
-            traffic = None
-    roof = {"bound": "hbm", "kernel": kname, "achieved": round(alg_launch / kdur / 1e9, 1) if kdur > 0 else None,
-            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg_launch / kdur / HBM_PEAK, 4) if kdur > 0 else None,
-            "traffic": traffic, "avg_launch_ms": round(kdur * 1e3, 4), "alg_bytes_per_launch": alg_launch,
-            "pass_ms": {names[i]: round(pass_s[i] * 1e3, 4) for i in range(3)},
-            "transform_frac": round(alg_bytes_transform / (dt / steps) / HBM_PEAK, 4),
-            "transform_device_ms": round(dev_s * 1e3, 4)}
+            return None
+    roof = roofline_block(pass_s, paired, multi, esz, E, world, dt / steps, dev_s, traffic_lookup)
     cplx = "double-complex" if prec == api.F64 else "single-complex"
     out = {"metric": f"3D FFT GFLOP/s ({n}^3 {cplx} forward, 5*E*log2(E) flop model)",
            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -365,8 +405,18 @@ def rank_main(args):
            "dtype": args.dtype, "data": "synthetic (seeded position hash, device-resident)",
            "config": {"workload": f"{n}^3 {cplx} forward 3-D FFT, in-place, offt_3d_execute",
                       "grid": [n, n, n], "mesh": f"{c['p1']}x{c['p2']}", "output_layout": args.layout,
-                      "steps_enqueued": "back to back, one wait (offt_hip_set_async + offt_hip_wait)" if multi else "one synchronous call per step"},
+                      "steps_enqueued": "one synchronous call per step"},
            "roofline": roof}
+    if multi:
+        # second figure, NOT the headline: the K steps enqueued back to back with one wait, as a caller that transforms a
+        # series of fields would do (no host round trip between steps)
+        try:
+            dt_p, _, _ = timed(po, data, steps, 1, enqueue_only=True)
+            out["ms_per_step_sync"] = round(ms, 4)
+            out["ms_per_step_pipelined"] = round(dt_p / steps * 1e3, 4)
+            out["value_pipelined"] = round(flops * steps / dt_p / 1e9, 1)
+        except Exception as e:
+            out["ms_per_step_pipelined_error"] = repr(e)
 
     # ---- N > 1: what bounds the run?  (everything below is outside the headline's timed region) ----
     if multi and not args.no_extras:
@@ -377,16 +427,12 @@ def rank_main(args):
             t_c, ps_c, _ = timed(po, data, ksteps, 1, skip=2)   # no exchanges
             t_x, _, _ = timed(po, data, ksteps, 1, skip=1)      # no FFT passes
             g = c["p2"] if c["p1"] == 1 else world
-            link_bytes = esz * E / world / g                    # per link and direction: (1/g) of the local volume to each of g-1 peers
             extra["headline_split"] = {
                 "compute_only_ms": round(t_c / ksteps * 1e3, 4), "exchange_only_ms": round(t_x / ksteps * 1e3, 4),
                 "full_ms": round(ms, 4),
                 "exposed_exchange_ms": round(max(0.0, ms - t_c / ksteps * 1e3), 4),
                 "kernels_hbm_frac": round(alg_bytes_transform / (t_c / ksteps) / HBM_PEAK, 4),
-                "xgmi": {"group": g, "links_used": g - 1, "bytes_per_link_per_direction": link_bytes,
-                         "achieved_GBps_per_link_per_direction": round(link_bytes / (t_x / ksteps) / 1e9, 2),
-                         "link_peak_GBps_bidirectional": XGMI_LINK / 1e9,
-                         "frac_of_link_bidirectional": round(2 * link_bytes / (t_x / ksteps) / XGMI_LINK, 4)}}
+                "xgmi": xgmi_block(g, esz, E, world, t_x / ksteps)}  # None for a group of one (one-GPU rehearsal)
         except Exception as e:  # extras never cost the headline
             extra["headline_split_error"] = repr(e)
         api.offt_3d_fin(po)
@@ -424,7 +470,8 @@ def rank_main(args):
             for label, mode, shift, nbytes in (("all_to_all_32MiB_per_peer", 0, 0, 32 << 20), ("ring_shift1_128MiB", 1, 1, 128 << 20)):
                 barrier()
                 sec = max_over_ranks(L.offt_hip_link_probe(mode, shift, nbytes, 3))
-                probe[label] = {"seconds": round(sec, 6), "GBps_per_link_per_direction": round(nbytes / sec / 1e9, 2) if sec > 0 else None}
+                probe[label] = {"seconds": round(sec, 6),  # (a world of one moves nothing: no rate)
+                                "GBps_per_link_per_direction": round(nbytes / sec / 1e9, 2) if sec > 0 and world > 1 else None}
             extra["link_probe"] = probe
         except Exception as e:
             extra["link_probe_error"] = repr(e)

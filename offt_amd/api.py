@@ -111,6 +111,8 @@ def bind(L):
     L.offt_hip_last_device_seconds.argtypes = [PP]
     L.offt_hip_last_pass_seconds.restype = None
     L.offt_hip_last_pass_seconds.argtypes = [PP, C.POINTER(C.c_double)]
+    L.offt_hip_last_passes_paired.restype = i
+    L.offt_hip_last_passes_paired.argtypes = [PP]
     L.offt_hip_last_error.restype = C.c_char_p
     L.offt_hip_malloc.restype = C.c_void_p
     L.offt_hip_malloc.argtypes = [C.c_longlong]

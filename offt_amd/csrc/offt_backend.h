@@ -37,6 +37,8 @@ typedef struct offt_backend {
   int (*a2a)(void *ctx, int which, int npeers, const int *peer, const void *const *sendp,
              const size_t *sendbytes, void *const *recvp, const size_t *recvbytes, void *stream);
   int (*memcpy_dd)(void *dst, const void *src, size_t bytes, void *stream);
+  /* host -> device copy of a small table, synchronous (plan time) */
+  int (*upload)(void *dst, const void *src, size_t bytes);
 } offt_backend;
 
 void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);

@@ -73,7 +73,7 @@ fft_bluestein_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::
         const int n = j + u * TPL + t * (M / RA);
         cx<T> x{(T)0, (T)0};
         if (valid && n < N) {
-          const V2 val = gload(&src[split_offset<decltype(has_split)::value>(n, a.in_split, a.in_inv, a.in_nfloor, a.in_lim, a.in_inv1, a.in_blk, a.in_axis)]);
+          const V2 val = gload(&src[split_offset<decltype(has_split)::value>(n, a.in_split, a.in_inv, a.in_nfloor, a.in_lim, a.in_inv1, a.in_blk, a.in_axis, a.in_tab)]);
           const V2 w = chirp[n];
           const T xi = xor_sign(val.y, conj_mask);
           x = cx<T>{val.x * w.x - xi * w.y, val.x * w.y + xi * w.x};
@@ -223,7 +223,7 @@ fft_bluestein_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::
           V2 o;
           o.x = (w.x * z.x + w.y * z.y) * sc;
           o.y = (w.y * z.x - w.x * z.y) * scy;
-          gstore(&dst[split_offset<decltype(has_split)::value>(n, a.out_split, a.out_inv, a.out_nfloor, a.out_lim, a.out_inv1, a.out_blk, a.out_axis)], o);
+          gstore(&dst[split_offset<decltype(has_split)::value>(n, a.out_split, a.out_inv, a.out_nfloor, a.out_lim, a.out_inv1, a.out_blk, a.out_axis, a.out_tab)], o);
         }
       });
     };

@@ -38,6 +38,13 @@ typedef struct offt_pass_desc {
   int in_split, in_split_nfloor;
   int out_split, out_split_nfloor;
   long long in_block_stride, out_block_stride;
+  /* per-block base table on a split side (device memory; NULL = block b sits at b * block_stride): tab[b] is the
+   * ELEMENT offset of axis block b relative to the launch's `in` / `out` pointer, for every block the axis has
+   * (ceil(n / split) of them; the number of peers for an uneven split).  The reference packs peer a's share into block
+   * a of ONE send buffer (offt-compute.c:1084-1109) which MPI then copies (835-881); with a table the blocks of one pass
+   * may live in different allocations -- the self block where the next pass reads it, a peer's block in that peer's
+   * receive volume (mapped through hipIpc) -- so the pack IS the exchange.  Offsets may be negative.                  */
+  const long long *in_block_tab, *out_block_tab;
   /* coalescing hints: 1 = the FFT axis is the unit-stride dimension,
    *                   0 = the column dimension is the unit-stride dimension    */
   int in_contig, out_contig;

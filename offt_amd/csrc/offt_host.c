@@ -398,12 +398,21 @@ typedef struct hip_state {
   void **send1, **recv1; /* ring */
   void **ev_k1, **ev_a1, **ev_k2;
   void *send2, *recv2;
+  /* per-block base tables of the packing passes (offt_pass_desc::out_block_tab, device memory): the block this rank keeps
+   * for itself is stored straight into the receive side, where the next pass reads it, and the exchange skips this rank */
+  int self_bypass;
+  long long *tab_s1;     /* slab schedule: K1's blocks into S1, the self block into R1 */
+  long long **tab_r1;    /* pencil schedule, per ring slot: K1's blocks into send1[r], the self block into recv1[r] */
+  long long *tab_x2;     /* pencil schedule: K2's blocks into send2, the self block into recv2 */
   ncclComm_t comm1, comm2; int have_comm1, have_comm2;
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
   int yx_fused;        /* the last single-rank execute alternated launches i and i+1 over groups of planes: i + 1 (0: none) */
   void *s_aux, *ev_aux[4]; /* ... with the x launches on this second stream, ordered behind their y launch by these events */
+  int k1_streams;      /* slab schedule: 2 = the K1 launches of consecutive x-tiles alternate between two streams, so that one tile's
+                          last workgroups and the next tile's first ones share the chip (a launch tail is ~7 % of a 190-us launch) */
+  void *s_k1b, *ev_fork;
   int wpad, wrow;      /* scratch volume W: extra elements per x-plane / per y-line (de-aliasing pads) */
   int async;
   int timed;            /* this call records timing events (synchronous call, or host-staged) */
@@ -500,9 +509,13 @@ static int hb_memcpy_dd(void *dst, const void *src, size_t bytes, void *s) {
   HCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s), return -1);
   return 0;
 }
+static int hb_upload(void *dst, const void *src, size_t bytes) {
+  HCHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), return -1);
+  return 0;
+}
 static const offt_backend k_hip_backend = {
     hb_malloc, hb_free, hb_prepare, hb_pass, hb_stream_create, hb_stream_destroy, hb_event_create,
-    hb_event_destroy, hb_event_record, hb_stream_wait, hb_stream_sync, hb_event_ms, hb_a2a, hb_memcpy_dd};
+    hb_event_destroy, hb_event_record, hb_stream_wait, hb_stream_sync, hb_event_ms, hb_a2a, hb_memcpy_dd, hb_upload};
 
 /* ------------------------------------------------------------------------- */
 /* helpers                                                                    */
@@ -536,6 +549,27 @@ static void desc_init(offt_pass_desc *d, const hip_state *st, int n, int dir, in
   d->scale = 1.0;
 }
 
+/* device copy of a per-block base table (offt_pass_desc::in_block_tab / out_block_tab): block b of the split axis sits
+ * b * stride elements behind the launch pointer, except the blocks of member `self` (nper consecutive blocks per group
+ * member), which sit `delta` elements further on -- in the receive buffer, where the next pass reads them.  This is the
+ * reference's pack into block a of a2as (offt-compute.c:1084-1109) with the copy to self that MPI_Ialltoall makes of
+ * block `rank` (835-881) folded into the pack. */
+static long long *tab_self(const hip_state *st, int members, int nper, long long stride, int self, long long delta) {
+  const int n = members * nper;
+  long long *h = (long long *)malloc(sizeof(long long) * (size_t)n), *d = (long long *)st->be->dmalloc(sizeof(long long) * (size_t)n);
+  if (!h || !d) { free(h); st->be->dfree(d); return NULL; }
+  for (int b = 0; b < n; b++) h[b] = (long long)b * stride + (b / nper == self ? delta : 0);
+  if (st->be->upload(d, h, sizeof(long long) * (size_t)n)) { st->be->dfree(d); d = NULL; }
+  free(h);
+  return d;
+}
+/* distance between two buffers in elements; 0 with *ok = 0 when it is not a whole (for single precision: even) number */
+static long long elem_delta(const hip_state *st, const void *to, const void *from, int *ok) {
+  const long long db = (long long)((const char *)to - (const char *)from);
+  if (db % 16) { *ok = 0; return 0; }
+  return db / (long long)st->esz;
+}
+
 /* ------------------------------------------------------------------------- */
 /* plan                                                                       */
 /* ------------------------------------------------------------------------- */
@@ -558,6 +592,9 @@ static void ring_teardown(hip_state *st) {
   if (st->recv1 != st->send1) free(st->recv1);
   free(st->send1);
   free(st->ev_k1); free(st->ev_a1); free(st->ev_k2);
+  for (int r = 0; r < st->ring && st->tab_r1; r++) be->dfree(st->tab_r1[r]);
+  free(st->tab_r1); st->tab_r1 = NULL;
+  be->dfree(st->tab_x2); st->tab_x2 = NULL;
   st->send1 = st->recv1 = NULL; st->ev_k1 = st->ev_a1 = st->ev_k2 = NULL;
   st->ring = 0;
   for (int h = 0; h < st->H2 && st->ev_a2; h++) be->event_destroy(st->ev_a2[h]);
@@ -624,6 +661,23 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (!st->recv2 || !st->send2) return -1;
   st->ev_a2 = (void **)calloc(st->H2, sizeof(void *));
   for (int h = 0; h < st->H2; h++) st->ev_a2[h] = be->event_create();
+  /* self blocks bypass the exchanges (see tab_self): K1 stores its own z-block into recv1[r], K2 its own y-block into recv2 */
+  if (st->self_bypass && st->x1 && c->p2 > 1) {
+    int ok = 1;
+    st->tab_r1 = (long long **)calloc(st->ring, sizeof(long long *));
+    for (int r = 0; r < st->ring && ok; r++) {
+      const long long delta = elem_delta(st, st->recv1[r], st->send1[r], &ok);
+      if (ok) st->tab_r1[r] = tab_self(st, c->p2, 1, (long long)st->blk1, po->rank % c->p2, delta);
+      if (!st->tab_r1[r]) ok = 0;
+    }
+    if (!ok) { for (int r = 0; r < st->ring; r++) be->dfree(st->tab_r1[r]); free(st->tab_r1); st->tab_r1 = NULL; }
+  }
+  if (st->self_bypass && st->x2 && c->p1 > 1) {
+    int ok = 1;
+    const long long delta = elem_delta(st, st->recv2, st->send2, &ok);
+    const long long stride = st->pencil_yc ? (long long)st->ntiles * st->H2 * ((long long)Tz * c->M4 * st->T) : (long long)st->blk2;
+    if (ok) st->tab_x2 = tab_self(st, c->p1, 1, stride, po->rank / c->p2, delta);
+  }
   return 0;
 }
 
@@ -687,6 +741,8 @@ static void state_free(hip_state *st) {
   for (int i = 0; i < 4; i++) be->event_destroy(st->evp[i]);
   if (st->own_stream) be->stream_destroy(st->s_compute);
   if (st->s_aux) be->stream_destroy(st->s_aux);
+  if (st->s_k1b) be->stream_destroy(st->s_k1b);
+  if (st->ev_fork) be->event_destroy(st->ev_fork);
   for (int i = 0; i < 4; i++) if (st->ev_aux[i]) be->event_destroy(st->ev_aux[i]);
   if (st->s_comm2 != st->s_comm1) be->stream_destroy(st->s_comm2);
   be->stream_destroy(st->s_comm1);
@@ -731,6 +787,8 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->be = g_backend ? g_backend : &k_hip_backend;
   st->variant[0] = st->variant[1] = st->variant[2] = -1;
   st->out_scale = 1.0;
+  st->self_bypass = !(getenv("OFFT_SELF_BYPASS") && atoi(getenv("OFFT_SELF_BYPASS")) == 0);
+  st->k1_streams = getenv("OFFT_K1_STREAMS") ? atoi(getenv("OFFT_K1_STREAMS")) : 1;
   /* scratch planes are offset by an odd number of 128-B lines (9 = 1152 B) so that the x-planes a
    * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt).  In
    * elements that is 72 for double and 144 for single precision: the 72 single-precision elements of r01
@@ -1114,6 +1172,7 @@ void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
 }
 double offt_hip_last_device_seconds(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->last_dev_s; }
+int offt_hip_last_passes_paired(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->yx_fused != 0; }
 void offt_hip_last_pass_seconds(const struct _offt_plan *po, double t[3]) {
   const hip_state *st = (const hip_state *)po->hip_state;
   t[0] = st->pass_s[0]; t[1] = st->pass_s[1]; t[2] = st->pass_s[2];
@@ -1401,6 +1460,7 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
       d.out_axis_stride = f.in_axis_stride; d.out_col_stride = f.in_col_stride; d.out_b1_stride = f.in_b1_stride; d.out_b2_stride = f.in_b2_stride;
       d.in_split = f.out_split; d.in_split_nfloor = f.out_split_nfloor; d.in_block_stride = f.out_block_stride;
       d.out_split = f.in_split; d.out_split_nfloor = f.in_split_nfloor; d.out_block_stride = f.in_block_stride;
+      d.in_block_tab = f.out_block_tab; d.out_block_tab = f.in_block_tab;
       d.in_contig = f.out_contig; d.out_contig = f.in_contig;
       d.scale = e->first ? st->out_scale : 1.0;
       rc = be->pass(&d, e->dst, (void *)e->src, s);
@@ -1449,6 +1509,7 @@ static void slab_teardown(hip_state *st) {
   const offt_backend *be = st->be;
   be->dfree(st->S1); be->dfree(st->R1); be->dfree(st->R2);
   st->S1 = st->R1 = st->R2 = NULL;
+  be->dfree(st->tab_s1); st->tab_s1 = NULL;
   for (int i = 0; i < st->sNt && st->ev_s1; i++) be->event_destroy(st->ev_s1[i]);
   for (int h = 0; h < st->sH && st->ev_sa; h++) be->event_destroy(st->ev_sa[h]);
   free(st->ev_s1); st->ev_s1 = NULL;
@@ -1494,6 +1555,14 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->ev_sa = (void **)calloc(st->sH, sizeof(void *));
   for (int i = 0; i < st->sNt; i++) st->ev_s1[i] = be->event_create();
   for (int h = 0; h < st->sH; h++) st->ev_sa[h] = be->event_create();
+  /* the self block bypasses the exchange (see tab_self): K1 stores this rank's own z-block straight into R1.  In the
+   * y-contiguous layout a peer's share is sH chunk blocks of the split, otherwise one block */
+  if (st->self_bypass && st->x1 && c->p2 > 1) {
+    int ok = 1;
+    const long long delta = elem_delta(st, st->R1, st->S1, &ok);
+    if (ok) st->tab_s1 = st->slab_yc ? tab_self(st, c->p2, st->sH, (long long)c->M2 * Tz * T * st->sNt, po->rank % c->p2, delta)
+                                     : tab_self(st, c->p2, 1, (long long)st->sblkS, po->rank % c->p2, delta);
+  }
   return 0;
 }
 
@@ -1510,7 +1579,14 @@ static int execute_slab(struct _offt_plan *po, void *data) {
 
   /* ---- K1: FFTz + pack (offt-compute.c:905-1206), all x-tiles ---- */
   be->event_record(st->evp[0], s);
+  int two = st->k1_streams >= 2 && nt > 1 && !st->rec;
+  if (two && !st->s_k1b) {
+    st->s_k1b = be->stream_create(); st->ev_fork = be->event_create();
+    if (!st->s_k1b || !st->ev_fork) two = 0;
+  }
+  if (two) { be->event_record(st->ev_fork, s); be->stream_wait(st->s_k1b, st->ev_fork); }
   for (int i = 0; i < nt; i++) {
+    void *sk = (two && (i & 1)) ? st->s_k1b : s; /* odd tiles on the second stream */
     const int x0 = i * T;
     int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
     if (myT > 0 && c->m2 > 0) {
@@ -1531,11 +1607,13 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
         if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
       }
+      d.out_block_tab = st->tab_s1; /* (relative to k1dst: the tile offset is the same in S1 and R1) */
       char *k1dst = (char *)st->S1 + (st->slab_yc ? (size_t)i * c->M2 * Tz * T : (size_t)i * p2 * st->sblkS) * esz;
-      if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, k1dst, s, 1)) return -1;
+      if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, k1dst, sk, 1)) return -1;
     }
-    be->event_record(st->ev_s1[i], s);
+    be->event_record(st->ev_s1[i], sk);
   }
+  if (two) be->stream_wait(s, st->ev_s1[((nt - 1) & 1) ? nt - 1 : nt - 2]); /* the last odd tile: the second stream joins */
   be->event_record(st->evp[1], s);
 
   /* ---- exchange: communicate_a2a (offt-compute.c:862-881), z-chunk-major.  Chunk 0 goes tile by
@@ -1552,13 +1630,14 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       const int merged = st->slab_yc && h > 0;
       const int groups = (h == 0) ? nt : 1, per = (h == 0 || merged) ? 1 : nt;
       for (int g = 0; g < groups; g++) {
-        const int cnt = per * p2;
-        const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
+        int cnt = 0;
+        const void *sp[per * p2]; void *rp[per * p2]; size_t sb[per * p2], rb[per * p2]; int pr[per * p2];
         if (h == 0) be->stream_wait(sc, st->ev_s1[g]);
         for (int ii = 0; ii < per; ii++) {
           const int i = (h == 0) ? g : ii;
           for (int a = 0; a < p2; a++) {
-            const int e = ii * p2 + a;
+            if (st->tab_s1 && a == po->rank % p2) continue; /* K1 stored this rank's own block straight into R1 */
+            const int e = cnt++;
             const size_t B = (size_t)c->M2 * Tz * T;
             const size_t off = st->slab_yc ? ((((size_t)a * H + h) * nt + (merged ? 0 : i)) * B) * esz
                                            : (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
@@ -1568,7 +1647,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
             sb[e] = rb[e] = (merged ? (size_t)nt : (size_t)1) * tz * c->M2 * T * esz;
           }
         }
-        if (run_a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
+        if (cnt && run_a2a(st, 1, cnt, pr, sp, sb, rp, rb, sc)) return -1;
       }
       be->event_record(st->ev_sa[h], sc);
     }
@@ -1690,6 +1769,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         if (p2 > 1) { /* peer a owns z in [a*F3, ..): offt-compute.c:1015-1027 */
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
+          if (st->tab_r1) d.out_block_tab = st->tab_r1[r];
         }
         if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s, 1)) return -1;
       }
@@ -1697,13 +1777,16 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
       if (st->x1) {
         be->stream_wait(st->s_comm1, st->ev_k1[r]);
-        const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2];
+        const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2]; int pr[p2], cnt = 0;
         for (int a = 0; a < p2; a++) {
-          sp[a] = (char *)st->send1[r] + (size_t)a * st->blk1 * esz;
-          rp[a] = (char *)st->recv1[r] + (size_t)a * st->blk1 * esz;
-          sb[a] = rb[a] = (size_t)myT * c->M2 * c->M3 * esz;
+          if (st->tab_r1 && a == po->rank % p2) continue; /* K1 stored this rank's own block straight into recv1[r] */
+          pr[cnt] = peers1[a];
+          sp[cnt] = (char *)st->send1[r] + (size_t)a * st->blk1 * esz;
+          rp[cnt] = (char *)st->recv1[r] + (size_t)a * st->blk1 * esz;
+          sb[cnt] = rb[cnt] = (size_t)myT * c->M2 * c->M3 * esz;
+          cnt++;
         }
-        if (myT > 0 && run_a2a(st, 1, p2, peers1, sp, sb, rp, rb, st->s_comm1)) return -1;
+        if (myT > 0 && cnt && run_a2a(st, 1, cnt, pr, sp, sb, rp, rb, st->s_comm1)) return -1;
         be->event_record(st->ev_a1[r], st->s_comm1);
       }
     }
@@ -1732,6 +1815,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
           d.out_block_stride = (long long)st->ntiles * H * B2;
+          d.out_block_tab = st->tab_x2; /* (relative to the launch pointer: tile / chunk offsets are the same in send2 and recv2) */
         }
         if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * H * B2 * esz, s, 0)) return -1;
       }
@@ -1756,6 +1840,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
           d.out_block_stride = (long long)st->blk2;
+          d.out_block_tab = st->tab_x2;
         }
         if (run_pass(st, &d, (char *)st->recv1[r] + (size_t)z0 * esz,
                      (char *)st->send2 + ((size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz, s, 0)) return -1;
@@ -1770,14 +1855,15 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         const int merged = st->pencil_yc && !last; /* one contiguous message per peer holds every chunk of the tile */
         const int ngroups = last ? H : 1, per = (last || merged) ? 1 : H;
         for (int g = 0; g < ngroups; g++) {
-          const int cnt = per * p1;
-          const void *sp[cnt]; void *rp[cnt]; size_t sb[cnt], rb[cnt]; int pr[cnt];
+          int cnt = 0;
+          const void *sp[per * p1]; void *rp[per * p1]; size_t sb[per * p1], rb[per * p1]; int pr[per * p1];
           int any = 0;
           for (int hh = 0; hh < per; hh++) {
             const int h = last ? g : hh, z0 = h * Tz;
             int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
             for (int a = 0; a < p1; a++) {
-              const int e = hh * p1 + a;
+              if (st->tab_x2 && a == po->rank / p2) continue; /* K2 stored this rank's own block straight into recv2 */
+              const int e = cnt++;
               int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
               const size_t off = st->pencil_yc
                                      ? (((size_t)a * st->ntiles + k) * H + (merged ? 0 : h)) * (size_t)Tz * c->M4 * T * esz

@@ -99,9 +99,10 @@ struct GenArgs {
   int nfac;
   int fac[OFFT_MIX_MAXFAC];
   double scale;
+  const long long *in_tab, *out_tab;  // per-block element offsets (offt_pass_desc::in_block_tab / out_block_tab) or nullptr
 };
 
-__device__ __forceinline__ long long split_off(int k, int split, int nfloor, long long blk, long long axis) {
+__device__ __forceinline__ long long split_off(int k, int split, int nfloor, long long blk, long long axis, const long long *tab) {
   if (split == 0 && nfloor == 0) return (long long)k * axis;  // no split
   int a, r;
   if (nfloor > 0 && k >= split * nfloor) {
@@ -112,7 +113,7 @@ __device__ __forceinline__ long long split_off(int k, int split, int nfloor, lon
     a = k / split;
     r = k % split;
   }
-  return (long long)a * blk + (long long)r * axis;
+  return (tab ? tab[a] : (long long)a * blk) + (long long)r * axis;
 }
 
 // one radix-R butterfly of the any-length kernel: inputs xin[t * is], t = 0..R-1, twiddled by
@@ -201,7 +202,7 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
     const V2 *src = in + ibase + (long long)(c0 + c) * a.in_col;
     V2 x;
     if (a.real_in) { x.x = reinterpret_cast<const T *>(src)[n]; x.y = 0; }
-    else x = src[split_off(n, a.in_split, a.in_nfloor, a.in_blk, a.in_axis)];
+    else x = src[split_off(n, a.in_split, a.in_nfloor, a.in_blk, a.in_axis, a.in_tab)];
     if (a.conj) x.y = -x.y;
     buf0[c * N + n] = x;
   }
@@ -267,7 +268,7 @@ fft_mixed_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type 
     w.x = v.x * (T)a.scale;
     w.y = (a.conj ? -v.y : v.y) * (T)a.scale;
     V2 *dst = out + obase + (long long)(c0 + c) * a.out_col;
-    dst[split_off(k, a.out_split, a.out_nfloor, a.out_blk, a.out_axis)] = w;
+    dst[split_off(k, a.out_split, a.out_nfloor, a.out_blk, a.out_axis, a.out_tab)] = w;
   }
 }
 
@@ -751,11 +752,12 @@ void xcd_order(long long nblk, unsigned *lim, unsigned *gshift) {
 bool pair_ok(const offt_pass_desc *d) {
   if (d->precision != OFFT_PREC_F32 || d->real_input || (d->ncols & 1)) return false;
   auto even = [](long long x) { return (x & 1) == 0; };
+  // (a per-block base table replaces the block stride; its entries are the host's to keep even: offt_host.c elem_delta)
   if (!d->in_contig && !(d->in_col_stride == 1 && even(d->in_axis_stride) && even(d->in_b1_stride) && even(d->in_b2_stride) &&
-                         even(d->in_block_stride)))
+                         ((d->in_split && d->in_block_tab) || even(d->in_block_stride))))
     return false;
   if (!d->out_contig && !(d->out_col_stride == 1 && even(d->out_axis_stride) && even(d->out_b1_stride) && even(d->out_b2_stride) &&
-                          even(d->out_block_stride)))
+                          ((d->out_split && d->out_block_tab) || even(d->out_block_stride))))
     return false;
   return true;
 }
@@ -912,6 +914,8 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.nb1 = d->nb1;
     a.conj = d->direction > 0;
     a.scale = d->scale;
+    a.in_tab = d->in_split ? d->in_block_tab : nullptr;
+    a.out_tab = d->out_split ? d->out_block_tab : nullptr;
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
     xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
@@ -955,6 +959,8 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   g.conj = d->direction > 0;
   g.real_in = d->real_input;
   g.scale = d->scale;
+  g.in_tab = d->in_split ? d->in_block_tab : nullptr;
+  g.out_tab = d->out_split ? d->out_block_tab : nullptr;
   // radices: prime factors, pairs of 2 merged into 4 (fewer LDS round trips at equal cost)
   g.nfac = 0;
   {

@@ -59,28 +59,19 @@ template <> struct lanes<f32x2> { using scalar = float; static constexpr int n =
 // global memory access helpers: 16-B (f64) / 8-B (f32) per lane.  Every element is
 // touched exactly once per pass, so loads and stores are non-temporal (streaming): A/B on
 // 1024^3 (profiles/r01_sweep.txt): -6 % transform time vs default cache policy.
-// -DOFFT_NO_NT_LOAD / -DOFFT_NO_NT_STORE restore the default policy for A/B builds.
 template <typename V2>
 __device__ __forceinline__ V2 gload(const V2 *p) {
-#ifndef OFFT_NO_NT_LOAD
   using E = decltype(p->x);
   typedef E vt __attribute__((ext_vector_type(2)));
   vt r = __builtin_nontemporal_load(reinterpret_cast<const vt *>(p));
   V2 o; o.x = r.x; o.y = r.y; return o;
-#else
-  return *p;
-#endif
 }
 template <typename V2>
 __device__ __forceinline__ void gstore(V2 *p, V2 v) {
-#ifndef OFFT_NO_NT_STORE
   using E = decltype(p->x);
   typedef E vt __attribute__((ext_vector_type(2)));
   vt r; r.x = v.x; r.y = v.y;
   __builtin_nontemporal_store(r, reinterpret_cast<vt *>(p));
-#else
-  *p = v;
-#endif
 }
 
 template <bool KEEP, typename V2>
@@ -118,15 +109,16 @@ __device__ __forceinline__ unsigned panel_of_block(unsigned bid, unsigned lim, u
 // element offset of axis index n under a per-peer split (SPLIT = false: none): indices below lim = split * nfloor
 // sit in blocks of `split`, the others in blocks of split + 1 -- the reference's uneven A2AV partition
 // (offt-compute.c:132-144); an even split is the case lim >= N.
+// `tab` (offt_pass_desc::in_block_tab / out_block_tab): per-block element offsets replacing blk * blk_stride, or nullptr.
 template <bool SPLIT>
 __device__ __forceinline__ long long split_offset(int n, int split, float inv, int nfloor, int lim, float inv1, long long blk_stride,
-                                                  long long axis_stride) {
+                                                  long long axis_stride, const long long *tab = nullptr) {
   if constexpr (!SPLIT) return (long long)n * axis_stride;
   else {
     int blk, rem;
     if (n < lim) { blk = fdiv(n, split, inv); rem = n - blk * split; }
     else { const int m = n - lim, b = fdiv(m, split + 1, inv1); blk = nfloor + b; rem = m - b * (split + 1); }
-    return (long long)blk * blk_stride + (long long)rem * axis_stride;
+    return (tab ? tab[blk] : (long long)blk * blk_stride) + (long long)rem * axis_stride;
   }
 }
 
@@ -203,6 +195,7 @@ struct PassArgs {
   unsigned xcd_lim;         // XCD-aware panel order for blocks below this index (see panel_of_block), 0 = off
   unsigned xcd_gshift;      // log2 G, G = run of neighbouring panels one XCD takes
   double scale;
+  const long long *in_tab, *out_tab;  // per-block element offsets (offt_pass_desc::in_block_tab / out_block_tab) or nullptr
 };
 
 template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
@@ -241,12 +234,8 @@ struct PanelCfg {
     return NSTAGE > 1 ? TW_OFF + ((size_t)shared_entries + (size_t)t1_entries) * 2 * sizeof(typename lanes<T>::scalar) : 0;
   }
   static constexpr int wg_for(size_t lds) { return lds ? (int)(160 * 1024 / lds) : 8; }
-#ifdef OFFT_NO_OPT_TW
-  static constexpr bool USE_T1 = false, USE_HALF = false;
-#else
   static constexpr bool USE_T1 = NSTAGE > 1 && wg_for(lds_with(QTQ, T1N)) == wg_for(lds_with(QTQ, 0));
   static constexpr bool USE_HALF = NSTAGE > 1 && N >= 16 && wg_for(lds_with(QTH, USE_T1 ? T1N : 0)) == wg_for(lds_with(QTQ, 0));
-#endif
   static constexpr int QT = USE_HALF ? QTH : QTQ;
   static constexpr size_t T1_OFF = TW_OFF + (size_t)QT * 2 * sizeof(typename lanes<T>::scalar);
   static constexpr size_t LDS_BYTES = lds_with(QT, USE_T1 ? T1N : 0);
@@ -317,11 +306,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   const int b1 = rest % (unsigned)a.nb1;
   const int b2 = rest / (unsigned)a.nb1;
   const int c0 = cp * COLS * NL;
-#ifdef OFFT_NO_OPT_CONJ
-  const unsigned conj_mask = 0u;
-#else
   const unsigned conj_mask = a.conj ? 0x80000000u : 0u;  // inverse transform = conj-in / conj-out: one XOR per element
-#endif
 
   cx<T> v[E];
 
@@ -343,9 +328,12 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     const int cl = (PAIR && !valid) ? 0 : c;
     const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)(c0 + cl * NL) * a.in_col;
     const int mask = (int)((1u << a.in_shift) - 1u);
-    auto load_all = [&](auto fast) {
-      constexpr bool FAST = decltype(fast)::value;
-      const V2 *p0 = src + ((FAST || PAIR) ? (long long)(j >> a.in_shift) * a.in_blk + (long long)(j & mask) * a.in_axis : 0LL);
+    // TAB: the blocks of the split come from a table of element offsets (in_block_tab) instead of blk * in_blk; block
+    // index and offset of n = j + cn are still the sums of those of j and cn, so the lookup index is (j >> shift) + (cn >> shift)
+    auto load_all = [&](auto tabbed) {
+      constexpr bool TAB = decltype(tabbed)::value;
+      const int jb = j >> a.in_shift;
+      const V2 *p0 = src + (TAB ? 0LL : (long long)jb * a.in_blk) + (long long)(j & mask) * a.in_axis;
       static_for<0, E>([&](auto ii) {
         constexpr int u = decltype(ii)::value / R0, t = decltype(ii)::value % R0;
         constexpr int cn = u * TPL + t * (N / R0);
@@ -358,37 +346,29 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
             if (valid) val.x = reinterpret_cast<const T *>(src)[n];
             v[decltype(ii)::value] = cx<T>{val.x, (T)0};
           }
-        } else if constexpr (PAIR) {
-          const long long off = (long long)(cn >> a.in_shift) * a.in_blk + (long long)(cn & mask) * a.in_axis;  // uniform
-          T re, im;
-          if constexpr (INC) {  // lanes along the line: one 8-B access per column
-            const V2 w0 = gload(p0 + off), w1 = gload(p0 + off + a.in_col);
-            re.x = w0.x; re.y = w1.x; im.x = w0.y; im.y = w1.y;
-          } else {              // lanes across columns: the pair is 16 contiguous bytes
-            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p0 + off));
-            re.x = q.x; im.x = q.y; re.y = q.z; im.y = q.w;
-          }
-          v[decltype(ii)::value] = cx<T>{re, xor_sign(im, conj_mask)};
         } else {
-          if constexpr (FAST) {
-            const long long off = (long long)(cn >> a.in_shift) * a.in_blk + (long long)(cn & mask) * a.in_axis;  // uniform
-            if (valid) val = gload(p0 + off);
+          long long off = (long long)(cn & mask) * a.in_axis;  // uniform
+          if constexpr (TAB) off += a.in_tab[jb + (cn >> a.in_shift)];
+          else off += (long long)(cn >> a.in_shift) * a.in_blk;  // uniform
+          if constexpr (PAIR) {
+            T re, im;
+            if constexpr (INC) {  // lanes along the line: one 8-B access per column
+              const V2 w0 = gload(p0 + off), w1 = gload(p0 + off + a.in_col);
+              re.x = w0.x; re.y = w1.x; im.x = w0.y; im.y = w1.y;
+            } else {              // lanes across columns: the pair is 16 contiguous bytes
+              const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p0 + off));
+              re.x = q.x; im.x = q.y; re.y = q.z; im.y = q.w;
+            }
+            v[decltype(ii)::value] = cx<T>{re, xor_sign(im, conj_mask)};
           } else {
-            if (valid) val = gload(&src[(long long)(n >> a.in_shift) * a.in_blk + (long long)(n & mask) * a.in_axis]);
+            if (valid) val = gload(p0 + off);
+            v[decltype(ii)::value] = cx<T>{val.x, xor_sign(val.y, conj_mask)};
           }
-#ifdef OFFT_NO_OPT_CONJ
-          v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
-#else
-          v[decltype(ii)::value] = cx<T>{val.x, xor_sign(val.y, conj_mask)};
-#endif
         }
       });
     };
-#ifdef OFFT_NO_OPT_ADDR
-    load_all(std::false_type{});
-#else
-    load_all(std::true_type{});
-#endif
+    if (a.in_tab) load_all(std::true_type{});
+    else load_all(std::false_type{});
   }
 
   // ---------------- stages ---------------------------------------------------
@@ -399,15 +379,12 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
     constexpr int NB = E / R;           // butterflies per thread
     constexpr int LR = ilog2(R);
 
-#ifndef OFFT_ABL_NOTW  /* developer ablation builds (tools/dev_ablate.sh): results are wrong, timings tell what a part costs */
     if constexpr (s > 0) {
       // inter-stage twiddles w_N^(k * t * N/(Ns*R)), k = q mod Ns
       constexpr int M = N / (Ns * R);
-#ifndef OFFT_NO_OPT_WAVESYNC
       // the twiddle tables staged at kernel entry must be visible: exchange 0 had a workgroup barrier unless it was
       // wave-private
       if constexpr (s == 1 && (64 % TPL == 0) && (NT % 64 == 0) && INC && !(NSTAGE == 2 && !OUTC)) __syncthreads();
-#endif
       static_for<0, NB>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
         const int q = j + u * TPL;
@@ -439,11 +416,8 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         });
       });
     }
-#endif
 
-#ifndef OFFT_ABL_NOBF
     static_for<0, NB>([&](auto uu) { dft_reg<T, R>(&v[decltype(uu)::value * R]); });
-#endif
 
     if constexpr (s < NSTAGE - 1) {
       // ---- exchange through LDS: write Stockham-ordered, read strided --------
@@ -467,13 +441,9 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       // barrier is needed -- waves drift apart and one wave's butterflies overlap another's LDS traffic.  Only an exchange
       // whose writer (stage 0 of a strided-in pass) or reader (last stage of a strided-out pass) runs lanes across
       // columns needs s_barrier.
-#ifdef OFFT_NO_OPT_WAVESYNC
-      constexpr bool PRIV = false, PRIV_W = false;
-#else
       constexpr bool WAVE_COLS = (64 % TPL == 0) && (NT % 64 == 0);
       constexpr bool PRIV_W = WAVE_COLS && (s > 0 || INC);                 // writer mapping is wave-private
       constexpr bool PRIV = PRIV_W && !(next_last && !OUTC);              // ... and so is the reader's
-#endif
       auto xsync = [&](auto priv) {
         if constexpr (decltype(priv)::value) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -483,7 +453,6 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
         }
       };
       // previous exchange's reads done (its reader mapping is this exchange's writer mapping)
-#ifndef OFFT_ABL_NOEX
       if constexpr (s > 0) xsync(std::integral_constant<bool, PRIV_W>{});
       constexpr std::integral_constant<bool, PRIV> priv{};
       if constexpr (SPLIT) {
@@ -524,7 +493,6 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
           else v[decltype(ii)::value] = cx<T>{w.x, w.y};
         });
       }
-#endif
       c = cn; j = jn;
     } else {
       // ---------------- last stage: global store ------------------------------
@@ -532,22 +500,21 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
       V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)(c0 + c * NL) * a.out_col;
       const int mask = (int)((1u << a.out_shift) - 1u);
       const S sc = (S)a.scale;
-#ifdef OFFT_NO_OPT_CONJ
-      const S scy = sc;
-#else
       const S scy = a.conj ? -sc : sc;  // conj-out rides on the scale
-#endif
-      auto store_all = [&](auto fast) {
-        constexpr bool FAST = decltype(fast)::value;
-        V2 *p0 = dst + ((FAST || PAIR) ? (long long)(j >> a.out_shift) * a.out_blk + (long long)(j & mask) * a.out_axis : 0LL);
+      auto store_all = [&](auto tabbed) {
+        constexpr bool TAB = decltype(tabbed)::value;  // blocks from out_block_tab (see the load side)
+        const int jb = j >> a.out_shift;
+        V2 *p0 = dst + (TAB ? 0LL : (long long)jb * a.out_blk) + (long long)(j & mask) * a.out_axis;
         static_for<0, E>([&](auto ii) {
           constexpr int u = decltype(ii)::value / R, t = decltype(ii)::value % R;
           constexpr int cn = u * TPL + t * (N / R);
           const int n = j + cn;
           cx<T> x = v[u * R + bitrev(t, LR)];
+          long long off = (long long)(cn & mask) * a.out_axis;  // uniform
+          if constexpr (TAB) off += a.out_tab[jb + (cn >> a.out_shift)];
+          else off += (long long)(cn >> a.out_shift) * a.out_blk;  // uniform
           if constexpr (PAIR) {
             const T wx = x.x * sc, wy = x.y * scy;
-            const long long off = (long long)(cn >> a.out_shift) * a.out_blk + (long long)(cn & mask) * a.out_axis;  // uniform
             if constexpr (OUTC) {
               V2 w0, w1;
               w0.x = wx.x; w0.y = wy.x; w1.x = wx.y; w1.y = wy.y;
@@ -560,29 +527,15 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
               else { if (valid) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(p0 + off)); }
             }
           } else {
-          V2 w;
-          w.x = x.x * sc;
-#ifdef OFFT_NO_OPT_CONJ
-          w.y = (a.conj ? -x.y : x.y) * sc;
-#else
-          w.y = x.y * scy;
-#endif
-          if (valid && (!R2C || n <= N / 2)) {
-            if constexpr (FAST) {
-              const long long off = (long long)(cn >> a.out_shift) * a.out_blk + (long long)(cn & mask) * a.out_axis;  // uniform
-              gstore_p<KEEP>(p0 + off, w);
-            } else {
-              gstore_p<KEEP>(&dst[(long long)(n >> a.out_shift) * a.out_blk + (long long)(n & mask) * a.out_axis], w);
-            }
-          }
+            V2 w;
+            w.x = x.x * sc;
+            w.y = x.y * scy;
+            if (valid && (!R2C || n <= N / 2)) gstore_p<KEEP>(p0 + off, w);
           }
         });
       };
-#ifdef OFFT_NO_OPT_ADDR
-      store_all(std::false_type{});
-#else
-      store_all(std::true_type{});
-#endif
+      if (a.out_tab) store_all(std::true_type{});
+      else store_all(std::false_type{});
     }
   });
 }
@@ -734,11 +687,7 @@ struct PanelXCfg {
   static constexpr int DATA_VGPR = EMAX * (int)sizeof(T) / 2;
   static constexpr int WPS_REG = DATA_VGPR >= 128 ? 2 : (DATA_VGPR >= 64 ? 3 : 4);
   static constexpr int WPS_MIN = (WAVES + 3) / 4;  // one workgroup must fit on a CU
-#ifdef OFFT_DEV_WPS  /* developer A/B: force the waves-per-SIMD target of the mixed-radix kernels */
-  static constexpr int WPS_E = OFFT_DEV_WPS;
-#else
   static constexpr int WPS_E = WPS < WPS_REG ? (WPS < WPS_MIN ? WPS_MIN : WPS) : (WPS_REG < WPS_MIN ? WPS_MIN : WPS_REG);
-#endif
 };
 
 template <typename T, int N, int TPL, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false>
@@ -799,7 +748,7 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
           v[decltype(ii)::value] = cx<T>{val.x, (T)0};
         } else {
           if (live)
-            val = gload(&src[split_offset<decltype(has_split)::value>(n, a.in_split, a.in_inv, a.in_nfloor, a.in_lim, a.in_inv1, a.in_blk, a.in_axis)]);
+            val = gload(&src[split_offset<decltype(has_split)::value>(n, a.in_split, a.in_inv, a.in_nfloor, a.in_lim, a.in_inv1, a.in_blk, a.in_axis, a.in_tab)]);
           v[decltype(ii)::value] = cx<T>{val.x, a.conj ? -val.y : val.y};
         }
       });
@@ -921,7 +870,7 @@ fft_panelx_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::typ
           w.y = (a.conj ? -x.y : x.y) * sc;
           const bool live = valid && ((u + 1) * TPL <= NBF || q < NBF);
           if (live && (!R2C || n <= N / 2))
-            gstore(&dst[split_offset<decltype(has_split)::value>(n, a.out_split, a.out_inv, a.out_nfloor, a.out_lim, a.out_inv1, a.out_blk, a.out_axis)], w);
+            gstore(&dst[split_offset<decltype(has_split)::value>(n, a.out_split, a.out_inv, a.out_nfloor, a.out_lim, a.out_inv1, a.out_blk, a.out_axis, a.out_tab)], w);
         });
       };
       if (a.out_split || a.out_nfloor) store_all(std::true_type{});

@@ -23,12 +23,12 @@ static void *cb_malloc(size_t b) { return calloc(1, b ? b : 16); }
 static void cb_free(void *p) { free(p); }
 static int cb_prepare(int n, int prec) { (void)n; (void)prec; return 0; }
 
-static long long split_off(int k, int split, int nfloor, long long blk, long long axis) {
+static long long split_off(int k, int split, int nfloor, long long blk, long long axis, const long long *tab) {
   if (split == 0 && nfloor == 0) return (long long)k * axis;
   int a, r;
   if (nfloor > 0 && k >= split * nfloor) { int kk = k - split * nfloor; a = nfloor + kk / (split + 1); r = kk % (split + 1); }
   else { a = k / split; r = k % split; }
-  return (long long)a * blk + (long long)r * axis;
+  return (tab ? tab[a] : (long long)a * blk) + (long long)r * axis; /* tab: offt_pass_desc::in_block_tab / out_block_tab */
 }
 
 static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *stream) {
@@ -44,7 +44,7 @@ static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
         long long ib = (long long)b1 * d->in_b1_stride + (long long)b2 * d->in_b2_stride + (long long)c * d->in_col_stride;
         long long ob = (long long)b1 * d->out_b1_stride + (long long)b2 * d->out_b2_stride + (long long)c * d->out_col_stride;
         for (int k = 0; k < n; k++) {
-          long long o = ib + split_off(k, d->in_split, d->in_split_nfloor, d->in_block_stride, d->in_axis_stride);
+          long long o = ib + split_off(k, d->in_split, d->in_split_nfloor, d->in_block_stride, d->in_axis_stride, d->in_block_tab);
           double re, im;
           if (d->real_input) { re = f32 ? ((const float *)in)[2 * ib + k] : ((const double *)in)[2 * ib + k]; im = 0.0; }
           else if (f32) { re = ((const float *)in)[2 * o]; im = ((const float *)in)[2 * o + 1]; }
@@ -53,7 +53,7 @@ static int cb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
         }
         orc_fft_execute(pl, line, 1, 0, 1, scr);
         for (int k = 0; k < (d->real_input ? n / 2 + 1 : n); k++) {
-          long long o = ob + split_off(k, d->out_split, d->out_split_nfloor, d->out_block_stride, d->out_axis_stride);
+          long long o = ob + split_off(k, d->out_split, d->out_split_nfloor, d->out_block_stride, d->out_axis_stride, d->out_block_tab);
           double re = line[2 * k] * d->scale, im = (d->direction > 0 ? -line[2 * k + 1] : line[2 * k + 1]) * d->scale;
           if (f32) { ((float *)out)[2 * o] = (float)re; ((float *)out)[2 * o + 1] = (float)im; }
           else { ((double *)out)[2 * o] = re; ((double *)out)[2 * o + 1] = im; }
@@ -84,9 +84,11 @@ static int cb_a2a(void *ctx, int which, int npeers, const int *peer, const void 
 }
 static int cb_memcpy_dd(void *dst, const void *src, size_t bytes, void *s) { (void)s; memmove(dst, src, bytes); return 0; }
 
+static int cb_upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+
 static const offt_backend k_cpu_backend = {cb_malloc, cb_free, cb_prepare, cb_pass, cb_stream_create, cb_stream_destroy,
                                            cb_event_create, cb_event_destroy, cb_event_record, cb_stream_wait,
-                                           cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd};
+                                           cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd, cb_upload};
 
 const offt_backend *cpu_backend_table(void) { return &k_cpu_backend; }
 /* run one descriptor on host arrays (descriptor-level parity tests against the HIP kernels) */

@@ -1,6 +1,7 @@
 """-m gpu: the kernel ABI (offt_hipk_fft_pass) against the test-only CPU interpreter of pass descriptors,
 on randomised descriptors: every (in_contig, out_contig) flavour, per-peer splits on either side (power-of-two,
-any other even length, uneven F/F+1), both batch dimensions, ragged column panels, inverse,
+any other even length, uneven F/F+1), blocks addressed through per-block base tables (the blocks of one pass in
+different places: self-bypass and direct-store exchange), both batch dimensions, ragged column panels, inverse,
 scale, real input, f32.  This is what the fused pack/unpack of the multi-GPU schedules rests on, and a one-GPU
 box cannot exercise those schedules with real peers."""
 import ctypes as C
@@ -25,6 +26,7 @@ class Desc(C.Structure):
                 ("out_b2_stride", C.c_longlong),
                 ("in_split", C.c_int), ("in_split_nfloor", C.c_int), ("out_split", C.c_int), ("out_split_nfloor", C.c_int),
                 ("in_block_stride", C.c_longlong), ("out_block_stride", C.c_longlong),
+                ("in_block_tab", C.c_void_p), ("out_block_tab", C.c_void_p),
                 ("in_contig", C.c_int), ("out_contig", C.c_int), ("variant", C.c_int), ("scale", C.c_double),
                 ("real_input", C.c_int), ("out_keep", C.c_int)]
 
@@ -88,6 +90,57 @@ def make_case(rng, n, prec, big_grid=False):
     return d, li["total"], lo["total"]
 
 
+def nblocks(n, split, nfloor):
+    if not (split or nfloor):
+        return 0
+    big = split + (1 if nfloor else 0)
+    return nfloor + (n - split * nfloor + big - 1) // big if nfloor else (n + split - 1) // split
+
+
+def with_tables(rng, d, nin, nout):
+    """move the blocks of the split sides to shuffled places behind the array (per-block base tables): returns the
+    enlarged element counts and the two tables (None where the side has no split).  The descriptor's block stride is
+    set to a value that would be wrong, so a kernel that ignores the table cannot pass."""
+    tabs = []
+    sizes = [nin, nout]
+    for side, (split, nfloor, blk) in enumerate(((d.in_split, d.in_split_nfloor, d.in_block_stride),
+                                                 (d.out_split, d.out_split_nfloor, d.out_block_stride))):
+        nb = nblocks(d.n, split, nfloor)
+        if not nb or rng.integers(0, 3) == 0:
+            tabs.append(None)
+            continue
+        span = sizes[side] + (sizes[side] & 1)               # (even: a column pair's 16 bytes stay aligned)
+        slots = rng.permutation(nb + 2)[:nb]                 # every block gets a region of its own ...
+        t = np.array([int(b) * blk + (int(s) + 1) * span for b, s in zip(range(nb), slots)], dtype=np.int64)
+        keep = rng.integers(0, nb)                           # ... and one of them stays where the stride puts it
+        t[keep] = int(keep) * blk
+        sizes[side] = span * (nb + 4)
+        tabs.append(t)
+        if side == 0:
+            d.in_block_stride = 1
+        else:
+            d.out_block_stride = 1
+    return sizes[0], sizes[1], tabs
+
+
+def run_both(L, CB, d, src, nout, ct, ft, tabs):
+    """descriptor on the CPU interpreter (host tables) and on the GPU (device tables) -> (want, got)"""
+    want = np.full(nout, 7 - 3j, dtype=ct)  # sentinel: untouched elements must stay untouched
+    d.in_block_tab = tabs[0].ctypes.data if tabs[0] is not None else None
+    d.out_block_tab = tabs[1].ctypes.data if tabs[1] is not None else None
+    assert CB.cpu_backend_run_pass(C.byref(d), src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p)) == 0
+    dt = [torch.from_numpy(t.copy()).cuda() if t is not None else None for t in tabs]
+    d.in_block_tab = dt[0].data_ptr() if dt[0] is not None else None
+    d.out_block_tab = dt[1].data_ptr() if dt[1] is not None else None
+    din = torch.from_numpy(src.view(ft).copy()).cuda()
+    dout = torch.from_numpy(np.full(nout, 7 - 3j, dtype=ct).view(ft).copy()).cuda()
+    torch.cuda.synchronize()
+    rc = L.offt_hipk_fft_pass(C.byref(d), din.data_ptr(), dout.data_ptr(), None)
+    assert rc == 0, L.offt_hipk_last_error()
+    torch.cuda.synchronize()
+    return want, dout.cpu().numpy().view(ct)
+
+
 @pytest.fixture(scope="module")
 def libs(built):
     L = api.lib()
@@ -110,18 +163,13 @@ def test_random_descriptors(libs, n):
     for prec in (api.F64, api.F32):
         assert L.offt_hipk_prepare(n, prec) == 0
         ft, ct = (np.float64, np.complex128) if prec == api.F64 else (np.float32, np.complex64)
-        for _ in range(REPS if n <= 512 else max(3, REPS // 2)):
+        for it in range(REPS if n <= 512 else max(3, REPS // 2)):
             d, nin, nout = make_case(rng, n, prec)
+            tabs = [None, None]
+            if it % 2 == 1:  # every other case: blocks through per-block base tables
+                nin, nout, tabs = with_tables(rng, d, nin, nout)
             src = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(ct)
-            want = np.full(nout, 7 - 3j, dtype=ct)  # sentinel: untouched elements must stay untouched
-            assert CB.cpu_backend_run_pass(C.byref(d), src.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p)) == 0
-            din = torch.from_numpy(src.view(ft).copy()).cuda()
-            dout = torch.from_numpy(np.full(nout, 7 - 3j, dtype=ct).view(ft).copy()).cuda()
-            torch.cuda.synchronize()
-            rc = L.offt_hipk_fft_pass(C.byref(d), din.data_ptr(), dout.data_ptr(), None)
-            assert rc == 0, L.offt_hipk_last_error()
-            torch.cuda.synchronize()
-            got = dout.cpu().numpy().view(ct)
+            want, got = run_both(L, CB, d, src, nout, ct, ft, tabs)
             tol = 1e-13 if prec == api.F64 else 5e-6
             scale = np.abs(want).max()
             desc = {f: getattr(d, f) for f, _ in Desc._fields_}
@@ -174,10 +222,18 @@ def test_column_pair_kernels(libs, n):
     assert L.offt_hipk_prepare(n, api.F32) == 0
     ct = np.complex64
 
-    def check(d, nin, nout, shift=0):
+    def check(d, nin, nout, shift=0, tables=False):
+        tabs = [None, None]
+        if tables:
+            nin, nout, tabs = with_tables(rng, d, nin, nout)
         src = (rng.standard_normal(nin + 1) + 1j * rng.standard_normal(nin + 1)).astype(ct)
         want = np.full(nout + 1, 7 - 3j, dtype=ct)
+        d.in_block_tab = tabs[0].ctypes.data if tabs[0] is not None else None
+        d.out_block_tab = tabs[1].ctypes.data if tabs[1] is not None else None
         assert CB.cpu_backend_run_pass(C.byref(d), src[shift:].ctypes.data_as(C.c_void_p), want[shift:].ctypes.data_as(C.c_void_p)) == 0
+        dt = [torch.from_numpy(t.copy()).cuda() if t is not None else None for t in tabs]
+        d.in_block_tab = dt[0].data_ptr() if dt[0] is not None else None
+        d.out_block_tab = dt[1].data_ptr() if dt[1] is not None else None
         din = torch.from_numpy(src.view(np.float32).copy()).cuda()
         dout = torch.from_numpy(np.full(nout + 1, 7 - 3j, dtype=ct).view(np.float32).copy()).cuda()
         torch.cuda.synchronize()
@@ -197,7 +253,7 @@ def test_column_pair_kernels(libs, n):
                 assert vid > 0, "no column-pair kernel registered for n=%d" % n
                 break
             seen += 1
-            check(d, nin, nout)
+            check(d, nin, nout, tables=bool(seen % 2))
     assert seen >= 6
     # not eligible: odd column count / an odd stride on a strided side / a misaligned base -> one-column kernels
     for _ in range(6):

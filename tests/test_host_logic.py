@@ -239,7 +239,11 @@ def test_gloo_world2(built, tmp_path):
              dict(N=[8, 8, 8], params=dict(P1=1, T1=2, T2=2), inv=1),
              # the defaults' own tiling (no 4 MiB message floor): T1 = M1/16, T2 = M3/16 merged to <= 8 chunks
              dict(N=[32, 16, 32], params=dict(P1=2), env=dict(OFFT_MIN_MSG=0)),
-             dict(N=[32, 16, 32], params=dict(P1=1), env=dict(OFFT_MIN_MSG=0))]
+             dict(N=[32, 16, 32], params=dict(P1=1), env=dict(OFFT_MIN_MSG=0)),
+             # the self block sent through the exchange like any other (OFFT_SELF_BYPASS=0; the default stores it straight
+             # into the receive side and tests/cpu_world.py asserts that no exchange carries it)
+             dict(N=[8, 8, 8], params=dict(P1=1, T1=2, T2=2), env=dict(OFFT_SELF_BYPASS=0)),
+             dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3), inv=1, env=dict(OFFT_SELF_BYPASS=0))]
     _run_world(2, cases, tmp_path)
 
 
@@ -250,7 +254,9 @@ def test_gloo_world4(built, tmp_path):
              dict(N=[10, 6, 9], params=dict(P1=2, T1=2, W1=1, T2=2)), dict(N=[12, 8, 10], params=dict(P1=4, T1=1, T2=3)),
              dict(N=[10, 6, 9], params=dict(P1=2, T1=2, T2=2), inv=1), dict(N=[16, 16, 16], params=dict(), env=dict(OFFT_MIN_MSG=0)),
              dict(N=[16, 8, 12], params=dict(P1=2, T1=2, T2=3)), dict(N=[16, 8, 12], params=dict(P1=4, T1=2, T2=4, S=1), inv=1),
-             dict(N=[16, 8, 12], params=dict(P1=2, T1=4, T2=2), env=dict(OFFT_PENCIL_ZC_LAYOUT=1))]
+             dict(N=[16, 8, 12], params=dict(P1=2, T1=4, T2=2), env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
+             dict(N=[16, 8, 12], params=dict(P1=2, T1=4, T2=2), env=dict(OFFT_SELF_BYPASS=0)),
+             dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2), inv=1, env=dict(OFFT_SELF_BYPASS=0))]
     _run_world(4, cases, tmp_path)
 
 
