@@ -68,6 +68,16 @@ int offt_hip_wait(struct _offt_plan *po);
 /* diagnostics for launchers: leave out the FFT passes (mask 1: exchange-only time) or the exchanges (mask 2:
  * compute-only time) of the multi-rank schedules.  Results are meaningless while a mask is set; 0 restores.       */
 void offt_hip_set_debug_skip(struct _offt_plan *po, int mask);
+/* exchange of a multi-rank plan.  STAGED (default): the packing passes fill a send volume, grouped RCCL send/recv moves
+ * it (the reference's pack + MPI_Ialltoall, offt-compute.c:1084-1109, 835-881); a rank's own block bypasses the exchange.
+ * DIRECT: the packing passes store every block straight into its owner's receive volume (peer memory mapped through
+ * hipIpc at plan time) and 64-bit flags replace the exchange -- no send volume, no copy kernels.  Collective: all ranks
+ * call it with the same mode.  Returns the mode in use afterwards (DIRECT falls back to STAGED on all ranks together where
+ * peer memory cannot be mapped), -1 on failure.  OFFT_EXCHANGE=p2p in the environment is the init-time default. */
+#define OFFT_HIP_EXCHANGE_STAGED 0
+#define OFFT_HIP_EXCHANGE_DIRECT 1
+int offt_hip_set_exchange(struct _offt_plan *po, int mode);
+int offt_hip_get_exchange(const struct _offt_plan *po);
 /* select a static-sweep kernel variant per axis (0 = x, 1 = y, 2 = z); -1 default */
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant);
 /* multiply the result by `scale` in the store of the last pass (1.0 = the reference's

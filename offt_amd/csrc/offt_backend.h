@@ -39,6 +39,18 @@ typedef struct offt_backend {
   int (*memcpy_dd)(void *dst, const void *src, size_t bytes, void *stream);
   /* host -> device copy of a small table, synchronous (plan time) */
   int (*upload)(void *dst, const void *src, size_t bytes);
+  /* ---- direct-store exchange (offt_host.c, "p2p") ----
+   * peer_open: collective over exchange group `which` (1 row / 2 column / 0 world) of npeers members, this rank being
+   * member `self`: every member offers the allocation `local` and gets in peers[a] an address valid HERE for member a's
+   * (peers[self] = local).  Non-zero: this backend cannot map peer memory (the plan falls back to the staged exchange). */
+  int (*peer_open)(void *ctx, int which, int npeers, int self, void *local, size_t bytes, void **peers);
+  void (*peer_close)(void *ctx, int npeers, int self, void **peers);
+  /* zeroed 64-bit words that peers write and this rank polls / a status word the host can read while a kernel may still write it */
+  void *(*flag_alloc)(size_t bytes, int host_visible);
+  void (*flag_free)(void *p, int host_visible);
+  /* offt_hipk_flag_signal / offt_hipk_flag_wait (offt_hipk.h) */
+  int (*flag_signal)(int n, unsigned long long *const *addr, unsigned long long value, void *stream);
+  int (*flag_wait)(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status, double timeout_s, void *stream);
 } offt_backend;
 
 void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
@@ -48,6 +60,14 @@ void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
 typedef int (*offt_test_transport_fn)(int which, int npeers, const int *peer, const void *const *sendp,
                                       const size_t *sendbytes, void *const *recvp, const size_t *recvbytes);
 void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size);
+/* several ranks as threads of ONE process (one GPU, or the CPU backend): hipIpc cannot open a handle in the process that
+ * made it, so peer_open goes through `fn` (same arguments as offt_backend::peer_open without ctx), which hands out the
+ * other threads' pointers; `hook` is called before every wait the direct-store schedule enqueues -- a barrier among the
+ * rank threads there guarantees that every signal a wait depends on is already enqueued (streams of one process may
+ * share a hardware queue, where a wait kernel ahead of the signal it waits for would never end). */
+typedef int (*offt_test_peer_open_fn)(int which, int npeers, int self, void *local, size_t bytes, void **peers);
+typedef void (*offt_test_hook_fn)(void);
+void offt_hip_test_set_p2p(offt_test_peer_open_fn fn, offt_test_hook_fn hook);
 /* p1 of the plan whose exchange is in progress on this thread: with it a transport maps (which, group member) to a
  * world rank -- which 1 = row group (rank_x * p2 + member), 2 = column group (member * p2 + rank_y), 0 = world   */
 int offt_hip_test_current_p1(void);

@@ -88,6 +88,17 @@ int offt_hipk_copy3d(const void *in, void *out, int precision,
 int offt_hipk_fill(void *buf, int precision, int kind,
                    int n0, int n1, int n2, int s0, int s1, int s2,
                    long long st0, long long st1, long long st2, void *stream);
+/* ---- flags of the direct-store exchange (offt_host.c, p2p mode) ----------------------------------------------------
+ * A rank that has stored its blocks straight into its peers' receive volumes tells them so by writing a monotonically
+ * growing value into one 64-bit word per peer (the role MPI_Wait plays behind MPI_Ialltoall, offt-compute.c:883-890);
+ * the peers wait for the words of all their senders before the next pass reads.  Both are one-wave launches on the
+ * stream: the signal is ordered behind the kernel that stored (whose end-of-kernel release has written its data back),
+ * the wait holds the stream until every word has reached `value` or `timeout_s` seconds have passed -- then it writes 1
+ * into *status (host-mapped or device memory) and gives up, so that a dead peer ends as an error, never as a hung GPU. */
+#define OFFT_HIPK_MAX_FLAGS 16
+int offt_hipk_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream);
+int offt_hipk_flag_wait(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status,
+                        double timeout_s, void *stream);
 const char *offt_hipk_last_error(void);
 
 #ifdef __cplusplus

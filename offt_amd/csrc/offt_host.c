@@ -136,6 +136,7 @@ typedef struct world_state {
 static world_state G_proc = {0, 1, 0, 0, NULL, 0};
 
 static int is_device_ptr(const void *p);
+static int world_max(struct _offt_plan *po, double *v);
 static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _offt_params *custom);
 struct hip_state;
 static void slab_teardown(struct hip_state *st);
@@ -197,7 +198,7 @@ int offt_hip_set_world(int rank, int size, const void *id128, int device) {
 int offt_hip_finalize_world(void) {
   if (G.have_comm) {
     /* after a communication failure the communicator's kernels may still be spinning: abort, do not wait */
-    if (G.comm_failed && R.CommAbort) (void)R.CommAbort(G.world);
+    if (G.comm_failed) { if (R.CommAbort) (void)R.CommAbort(G.world); /* else: leaked, ncclCommDestroy could block for ever */ }
     else (void)R.CommDestroy(G.world);
     G.have_comm = 0; G.world = NULL;
   }
@@ -404,12 +405,24 @@ typedef struct hip_state {
   long long *tab_s1;     /* slab schedule: K1's blocks into S1, the self block into R1 */
   long long **tab_r1;    /* pencil schedule, per ring slot: K1's blocks into send1[r], the self block into recv1[r] */
   long long *tab_x2;     /* pencil schedule: K2's blocks into send2, the self block into recv2 */
+  /* direct-store exchange ("p2p", offt_hip_set_exchange / OFFT_EXCHANGE=p2p): the packing passes store every block
+   * straight into the receive volume of the rank it is for (peer memory mapped at plan time), flags say when */
+  int want_p2p;          /* asked for */
+  int p2p;               /* in use by this mesh (every rank could map its peers) */
+  struct p2p_group { int which, n, self, nslots; unsigned long long *flags, **pflags; } g1, g2;
+  void **peer_r1, **peer_x2; /* the group members' receive volumes: exchange 1 (R1 / the recv1 ring), exchange 2 (recv2) */
+  void *recv1_base;      /* pencil schedule: the recv1 ring as ONE allocation (one mapping per peer) */
+  long long *tab_p1, **tab_pr, *tab_p2; /* per-block base tables into the peers' volumes: slab K1, pencil K1 per ring slot, pencil K2 */
+  unsigned long long epoch, *use1, tiles2, bar1, bar2; /* flag values: transforms done, uses of each ring slot, tiles sent in exchange 2, barriers */
+  unsigned long long *p2p_status; /* host-visible: a wait kernel gave up */
   ncclComm_t comm1, comm2; int have_comm1, have_comm2;
   void *stage; size_t stage_bytes;
   int variant[3];
   double out_scale;
   int yx_fused;        /* the last single-rank execute alternated launches i and i+1 over groups of planes: i + 1 (0: none) */
   void *s_aux, *ev_aux[4]; /* ... with the x launches on this second stream, ordered behind their y launch by these events */
+  double *agree_d, *agree_h; /* world_max(): 2 p doubles on the device and on the host, made once at plan time so that the
+                                agreement itself never allocates (it runs right after a rank may have run out of memory) */
   int k1_streams;      /* slab schedule: 2 = the K1 launches of consecutive x-tiles alternate between two streams, so that one tile's
                           last workgroups and the next tile's first ones share the chip (a launch tail is ~7 % of a 190-us launch) */
   void *s_k1b, *ev_fork;
@@ -513,9 +526,92 @@ static int hb_upload(void *dst, const void *src, size_t bytes) {
   HCHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), return -1);
   return 0;
 }
+#ifdef OFFT_TEST_SEAMS
+static _Thread_local offt_test_peer_open_fn g_test_peer_open = NULL;
+static _Thread_local offt_test_hook_fn g_test_p2p_hook = NULL;
+void offt_hip_test_set_p2p(offt_test_peer_open_fn fn, offt_test_hook_fn hook) { g_test_peer_open = fn; g_test_p2p_hook = hook; }
+#define P2P_HOOK() do { if (g_test_p2p_hook) g_test_p2p_hook(); } while (0)
+#else
+#define g_test_peer_open ((offt_test_peer_open_fn)NULL)
+#define P2P_HOOK() ((void)0)
+#endif
+
+/* map the group members' allocations (offt_backend::peer_open): hipIpc handles, gathered with the group's own exchange
+ * primitive (64 bytes to and from every member), opened with peer access enabled on first use.  What the reference gets
+ * from MPI for free -- the library moves the packed blocks -- becomes an address the packing kernel can store to. */
+static int hb_peer_open(void *ctx, int which, int n, int self, void *local, size_t bytes, void **peers) {
+  hip_state *st = (hip_state *)ctx;
+  if (g_test_peer_open) return g_test_peer_open(which, n, self, local, bytes, peers);
+  (void)bytes;
+  const size_t HB = sizeof(hipIpcMemHandle_t);
+  hipIpcMemHandle_t mine;
+  char *d = NULL, *h = (char *)malloc(2 * HB * (size_t)n);
+  int rc = -1;
+  if (!h) return -1;
+  if (hipIpcGetMemHandle(&mine, local) != hipSuccess) { (void)hipGetLastError(); goto out; }
+  if (hipMalloc((void **)&d, 2 * HB * (size_t)n) != hipSuccess) { (void)hipGetLastError(); d = NULL; goto out; }
+  for (int a = 0; a < n; a++) memcpy(h + (size_t)a * HB, &mine, HB);
+  memset(h + HB * (size_t)n, 0, HB * (size_t)n);
+  if (hipMemcpy(d, h, 2 * HB * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) goto out;
+  {
+    const void *sp[n]; void *rp[n]; size_t sb[n], rb[n]; int pr[n];
+    for (int a = 0; a < n; a++) { pr[a] = a; sp[a] = d + (size_t)a * HB; rp[a] = d + (size_t)(n + a) * HB; sb[a] = rb[a] = HB; }
+    if (hb_a2a(st, which, n, pr, sp, sb, rp, rb, st->s_compute)) goto out;
+    if (hipStreamSynchronize((hipStream_t)st->s_compute) != hipSuccess) goto out;
+  }
+  if (hipMemcpy(h, d, 2 * HB * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) goto out;
+  rc = 0;
+  for (int a = 0; a < n; a++) peers[a] = NULL;
+  for (int a = 0; a < n; a++) {
+    if (a == self) { peers[a] = local; continue; }
+    hipIpcMemHandle_t hm;
+    memcpy(&hm, h + (size_t)(n + a) * HB, HB);
+    if (hipIpcOpenMemHandle(&peers[a], hm, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      SET_ERR("hipIpcOpenMemHandle for group %d member %d failed: %s", which, a, hipGetErrorString(hipGetLastError()));
+      peers[a] = NULL; rc = -1;
+    }
+  }
+  if (rc) for (int a = 0; a < n; a++) if (a != self && peers[a]) { (void)hipIpcCloseMemHandle(peers[a]); peers[a] = NULL; }
+out:
+  if (d) (void)hipFree(d);
+  free(h);
+  return rc;
+}
+static void hb_peer_close(void *ctx, int n, int self, void **peers) {
+  (void)ctx;
+  if (g_test_peer_open || !peers) return;
+  for (int a = 0; a < n; a++) if (a != self && peers[a]) (void)hipIpcCloseMemHandle(peers[a]);
+}
+static void *hb_flag_alloc(size_t bytes, int host_visible) {
+  void *p = NULL;
+  if (host_visible) {
+    HCHECK(hipHostMalloc(&p, bytes, hipHostMallocMapped), return NULL);
+    memset(p, 0, bytes);
+    return p;
+  }
+  HCHECK(hipMalloc(&p, bytes), return NULL);
+  HCHECK(hipMemset(p, 0, bytes), { (void)hipFree(p); return NULL; });
+  HCHECK(hipDeviceSynchronize(), { (void)hipFree(p); return NULL; });
+  return p;
+}
+static void hb_flag_free(void *p, int host_visible) {
+  if (!p) return;
+  if (host_visible) (void)hipHostFree(p); else (void)hipFree(p);
+}
+static int hb_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream) {
+  const int rc = offt_hipk_flag_signal(n, addr, value, stream);
+  if (rc) SET_ERR("flag signal failed: %s", offt_hipk_last_error());
+  return rc;
+}
+static int hb_flag_wait(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status, double timeout_s, void *stream) {
+  const int rc = offt_hipk_flag_wait(n, addr, value, status, timeout_s, stream);
+  if (rc) SET_ERR("flag wait failed: %s", offt_hipk_last_error());
+  return rc;
+}
 static const offt_backend k_hip_backend = {
     hb_malloc, hb_free, hb_prepare, hb_pass, hb_stream_create, hb_stream_destroy, hb_event_create,
-    hb_event_destroy, hb_event_record, hb_stream_wait, hb_stream_sync, hb_event_ms, hb_a2a, hb_memcpy_dd, hb_upload};
+    hb_event_destroy, hb_event_record, hb_stream_wait, hb_stream_sync, hb_event_ms, hb_a2a, hb_memcpy_dd, hb_upload,
+    hb_peer_open, hb_peer_close, hb_flag_alloc, hb_flag_free, hb_flag_signal, hb_flag_wait};
 
 /* ------------------------------------------------------------------------- */
 /* helpers                                                                    */
@@ -571,6 +667,83 @@ static long long elem_delta(const hip_state *st, const void *to, const void *fro
 }
 
 /* ------------------------------------------------------------------------- */
+/* direct-store exchange ("p2p"): groups, flags, tables                        */
+/*                                                                           */
+/* The reference packs peer a's share into block a of a send buffer           */
+/* (offt-compute.c:1084-1109) and MPI_Ialltoall copies block a into peer a's  */
+/* receive buffer, block `rank` (835-881).  Here the packing kernel stores     */
+/* block a straight into peer a's receive volume at sender slot `self`        */
+/* (per-block base tables, offt_hipk.h): no send volume, no copy kernel, the  */
+/* bytes cross xGMI once as 128-B stores.  What is left of the exchange is     */
+/* its completion: one 64-bit flag word per (slot, sender) in every rank's    */
+/* memory, written by the sender behind its kernel (flag_signal) and polled    */
+/* by a one-wave wait on the receiver's stream (flag_wait):                    */
+/*   READY  "my blocks of this tile / transform are in your volume"           */
+/*   FREE   "I have consumed what you stored: overwrite it"                   */
+/* Values only grow, so nothing is ever reset.                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct p2p_group p2p_group;
+static void p2p_group_close(hip_state *st, p2p_group *g) {
+  const offt_backend *be = st->be;
+  if (g->pflags) { be->peer_close(st, g->n, g->self, (void **)g->pflags); free(g->pflags); }
+  be->flag_free(g->flags, 0);
+  memset(g, 0, sizeof *g);
+}
+static int p2p_group_open(hip_state *st, p2p_group *g, int which, int n, int self, int nslots) {
+  const offt_backend *be = st->be;
+  memset(g, 0, sizeof *g);
+  g->which = which; g->n = n; g->self = self; g->nslots = nslots;
+  const size_t bytes = sizeof(unsigned long long) * (size_t)nslots * (size_t)n;
+  g->flags = (unsigned long long *)be->flag_alloc(bytes, 0);
+  g->pflags = (unsigned long long **)calloc((size_t)n, sizeof(void *));
+  if (!g->flags || !g->pflags) return -1;
+  return be->peer_open(st, which, n, self, g->flags, bytes, (void **)g->pflags);
+}
+/* flag words: slot-major, one word per sender */
+static int p2p_signal(hip_state *st, const p2p_group *g, int slot, unsigned long long value, void *stream) {
+  unsigned long long *addr[OFFT_HIPK_MAX_FLAGS];
+  for (int a = 0; a < g->n; a++) addr[a] = g->pflags[a] + (size_t)slot * g->n + g->self;
+  return st->be->flag_signal(g->n, addr, value, stream);
+}
+static int p2p_wait(hip_state *st, const p2p_group *g, int slot, unsigned long long value, void *stream) {
+  unsigned long long *addr[OFFT_HIPK_MAX_FLAGS];
+  if (value == 0) return 0;
+  for (int a = 0; a < g->n; a++) addr[a] = g->flags + (size_t)slot * g->n + a;
+  const double limit = getenv("OFFT_P2P_TIMEOUT") ? atof(getenv("OFFT_P2P_TIMEOUT")) : 30.0;
+  P2P_HOOK(); /* (thread worlds of the tests: every signal this wait depends on is enqueued by now) */
+  return st->be->flag_wait(g->n, addr, value, st->p2p_status, limit, stream);
+}
+/* per-block base table of a packing pass in p2p mode: block b (nper blocks per group member) goes into member b / nper's
+ * volume at sender slot `self`, i.e. (peer - mine) elements from the launch pointer (which is based on this rank's OWN
+ * receive volume) plus (self * nper + b % nper) * stride */
+static long long *tab_peers(const hip_state *st, int members, int nper, long long stride, int self, void *const *peer, const void *mine) {
+  const int n = members * nper;
+  long long *h = (long long *)malloc(sizeof(long long) * (size_t)n), *d = (long long *)st->be->dmalloc(sizeof(long long) * (size_t)n);
+  int ok = h && d;
+  for (int b = 0; b < n && ok; b++) {
+    const long long delta = elem_delta(st, peer[b / nper], mine, &ok);
+    h[b] = delta + ((long long)self * nper + b % nper) * stride;
+  }
+  if (ok && st->be->upload(d, h, sizeof(long long) * (size_t)n)) ok = 0;
+  free(h);
+  if (!ok) { st->be->dfree(d); return NULL; }
+  return d;
+}
+static void p2p_teardown(hip_state *st) {
+  const offt_backend *be = st->be;
+  if (st->peer_r1) { be->peer_close(st, st->g1.n, st->g1.self, st->peer_r1); free(st->peer_r1); st->peer_r1 = NULL; }
+  if (st->peer_x2) { be->peer_close(st, st->g2.n, st->g2.self, st->peer_x2); free(st->peer_x2); st->peer_x2 = NULL; }
+  if (st->g1.flags || st->g1.pflags) p2p_group_close(st, &st->g1);
+  if (st->g2.flags || st->g2.pflags) p2p_group_close(st, &st->g2);
+  be->dfree(st->tab_p1); st->tab_p1 = NULL;
+  be->dfree(st->tab_p2); st->tab_p2 = NULL;
+  if (st->tab_pr) { for (int r = 0; r < st->ring; r++) be->dfree(st->tab_pr[r]); free(st->tab_pr); st->tab_pr = NULL; }
+  free(st->use1); st->use1 = NULL;
+  be->flag_free(st->p2p_status, 1); st->p2p_status = NULL;
+  st->p2p = 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* plan                                                                       */
 /* ------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------- */
@@ -583,12 +756,13 @@ static long long elem_delta(const hip_state *st, const void *to, const void *fro
 static void ring_teardown(hip_state *st) {
   const offt_backend *be = st->be;
   for (int r = 0; r < st->ring; r++) {
-    if (st->send1) be->dfree(st->send1[r]);
-    if (st->recv1 && st->recv1 != st->send1) be->dfree(st->recv1[r]);
+    if (st->send1 && !st->recv1_base) be->dfree(st->send1[r]);
+    if (st->recv1 && st->recv1 != st->send1 && !st->recv1_base) be->dfree(st->recv1[r]);
     if (st->ev_k1) be->event_destroy(st->ev_k1[r]);
     if (st->ev_a1) be->event_destroy(st->ev_a1[r]);
     if (st->ev_k2) be->event_destroy(st->ev_k2[r]);
   }
+  be->dfree(st->recv1_base); st->recv1_base = NULL;
   if (st->recv1 != st->send1) free(st->recv1);
   free(st->send1);
   free(st->ev_k1); free(st->ev_a1); free(st->ev_k2);
@@ -628,13 +802,20 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (st->ring > st->ntiles) st->ring = st->ntiles;
   st->blk1 = (size_t)st->T * c->M2 * c->M3;
   st->send1 = (void **)calloc(st->ring, sizeof(void *));
-  st->recv1 = st->x1 ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
+  st->recv1 = (st->x1 && !st->p2p) ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
   st->ev_k1 = (void **)calloc(st->ring, sizeof(void *));
   st->ev_a1 = (void **)calloc(st->ring, sizeof(void *));
   st->ev_k2 = (void **)calloc(st->ring, sizeof(void *));
+  if (st->p2p) {
+    /* direct-store exchange: no send side; the receive ring is ONE allocation (one mapping per peer), slot r at r * slot bytes */
+    const size_t slot = ((st->blk1 * c->p2 * st->esz + 255) / 256) * 256;
+    st->recv1_base = be->dmalloc(slot * (size_t)st->ring);
+    if (!st->recv1_base) return -1;
+    for (int r = 0; r < st->ring; r++) st->send1[r] = (char *)st->recv1_base + (size_t)r * slot;
+  }
   for (int r = 0; r < st->ring; r++) {
-    st->send1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
-    if (st->x1) st->recv1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
+    if (!st->p2p) st->send1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
+    if (st->x1 && !st->p2p) st->recv1[r] = be->dmalloc(st->blk1 * c->p2 * st->esz);
     st->ev_k1[r] = be->event_create(); st->ev_a1[r] = be->event_create(); st->ev_k2[r] = be->event_create();
     if (!st->send1[r] || !st->recv1[r]) return -1;
   }
@@ -657,12 +838,12 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   st->pencil_yc = c->b1 == 0 && c->b3 == 0 && c->M1 % st->T == 0 && c->M3 % Tz == 0 &&
                   !(getenv("OFFT_PENCIL_ZC_LAYOUT") && atoi(getenv("OFFT_PENCIL_ZC_LAYOUT")));
   st->recv2 = be->dmalloc(st->blk2 * c->p1 * st->esz);
-  st->send2 = st->x2 ? be->dmalloc(st->blk2 * c->p1 * st->esz) : st->recv2;
+  st->send2 = (st->x2 && !st->p2p) ? be->dmalloc(st->blk2 * c->p1 * st->esz) : st->recv2;
   if (!st->recv2 || !st->send2) return -1;
   st->ev_a2 = (void **)calloc(st->H2, sizeof(void *));
   for (int h = 0; h < st->H2; h++) st->ev_a2[h] = be->event_create();
   /* self blocks bypass the exchanges (see tab_self): K1 stores its own z-block into recv1[r], K2 its own y-block into recv2 */
-  if (st->self_bypass && st->x1 && c->p2 > 1) {
+  if (st->self_bypass && st->x1 && c->p2 > 1 && !st->p2p) {
     int ok = 1;
     st->tab_r1 = (long long **)calloc(st->ring, sizeof(long long *));
     for (int r = 0; r < st->ring && ok; r++) {
@@ -672,7 +853,7 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
     }
     if (!ok) { for (int r = 0; r < st->ring; r++) be->dfree(st->tab_r1[r]); free(st->tab_r1); st->tab_r1 = NULL; }
   }
-  if (st->self_bypass && st->x2 && c->p1 > 1) {
+  if (st->self_bypass && st->x2 && c->p1 > 1 && !st->p2p) {
     int ok = 1;
     const long long delta = elem_delta(st, st->recv2, st->send2, &ok);
     const long long stride = st->pencil_yc ? (long long)st->ntiles * st->H2 * ((long long)Tz * c->M4 * st->T) : (long long)st->blk2;
@@ -688,27 +869,37 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
 /* rebuilds it per P1 candidate like the tuner does (offt-tuning.c:929).       */
 /* ------------------------------------------------------------------------- */
 static void mesh_teardown(hip_state *st) {
+  p2p_teardown(st); /* (before the buffers it maps) */
   ring_teardown(st);
   slab_teardown(st);
-  if (st->have_comm1) { (void)R.CommDestroy(st->comm1); st->have_comm1 = 0; }
-  if (st->have_comm2) { (void)R.CommDestroy(st->comm2); st->have_comm2 = 0; }
+  /* (after a communication failure without ncclCommAbort the communicators are leaked, not destroyed: see comm_fail) */
+  if (st->have_comm1) { if (!G.comm_failed) (void)R.CommDestroy(st->comm1); st->have_comm1 = 0; }
+  if (st->have_comm2) { if (!G.comm_failed) (void)R.CommDestroy(st->comm2); st->have_comm2 = 0; }
   st->comm1 = st->comm2 = NULL;
   st->uses_rccl = 0;
 }
 
+static int p2p_open(struct _offt_plan *po, hip_state *st);
 static int mesh_setup(struct _offt_plan *po, hip_state *st) {
   const struct _offt_comm *c = po->comm;
   const int p1 = c->p1, p2 = c->p2;
   const int force = getenv("OFFT_FORCE_A2A") && atoi(getenv("OFFT_FORCE_A2A"));
   st->x1 = (p2 > 1) || force;
   st->x2 = (p1 > 1) || force;
+  /* direct-store exchange: asked for, a real world, groups the flag kernels can address, complex input (the r2c z pass
+   * has no split side to put a table on when p2 == 1, and is not worth a special case) */
+  st->p2p = st->want_p2p && po->p > 1 && p1 <= OFFT_HIPK_MAX_FLAGS && p2 <= OFFT_HIPK_MAX_FLAGS && !force;
   st->slab_zyx = (p1 == 1) && !po->params->v[_S_] && !(po->is_equalxy && c->M1 == c->M4) &&
                  !(getenv("OFFT_NO_SLAB_LAYOUT") && atoi(getenv("OFFT_NO_SLAB_LAYOUT")));
   st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
+  /* the local part (buffers) may fail on ONE rank (out of memory); the collective part below -- ncclCommSplit has no
+   * time-out -- is therefore run by every rank whatever its local result, which is returned afterwards: the callers
+   * (offt_3d_init_ex, the static sweep) then agree on it across the world before anybody enters an exchange */
+  int rc_local = 0;
   if (st->slab_zyx) {
     st->x2 = 0; /* p1 == 1: there is no second exchange */
-    if (slab_setup(po, st)) return -1;
-  } else if (ring_setup(po, st)) return -1;
+    rc_local = slab_setup(po, st);
+  } else rc_local = ring_setup(po, st);
   if (!g_backend && !g_test_transport && (po->p > 1 || force)) {
     /* comm1: ranks sharing rank_x (contiguous), comm2: ranks sharing rank_y
      * (stride p2) -- offt-compute.c:78-125 */
@@ -728,6 +919,72 @@ static int mesh_setup(struct _offt_plan *po, hip_state *st) {
     }
     st->uses_rccl = st->x1 || st->x2;
   }
+  if (st->p2p) {
+    /* map the peers' volumes (collective).  Every rank first learns whether every rank has its buffers; afterwards
+     * whether every rank could map every peer -- if not, ALL ranks fall back to the staged exchange together. */
+    double bad = rc_local ? 1.0 : 0.0;
+    if (world_max(po, &bad) || bad > 0.0) return -1;
+    bad = p2p_open(po, st) ? 1.0 : 0.0;
+    if (world_max(po, &bad)) return -1;
+    if (bad > 0.0) {
+      if (!po->rank) fprintf(stderr, "offt(hip): direct-store exchange not available here (%s); using the staged RCCL exchange\n", g_err);
+      const int want = st->want_p2p;
+      mesh_teardown(st);
+      st->want_p2p = 0;
+      const int rc = mesh_setup(po, st);
+      st->want_p2p = want;
+      return rc;
+    }
+    st->uses_rccl = 0; /* the communicators were only needed to hand the mappings round */
+  }
+  return rc_local;
+}
+
+/* map what the packing passes store into and build their per-block tables (see the p2p block above) */
+static int p2p_open(struct _offt_plan *po, hip_state *st) {
+  const offt_backend *be = st->be;
+  const struct _offt_comm *c = po->comm;
+  const int p1 = c->p1, p2 = c->p2, rx = po->rank / p2, ry = po->rank % p2;
+  st->p2p_status = (unsigned long long *)be->flag_alloc(sizeof(unsigned long long), 1);
+  if (!st->p2p_status) return -1;
+  st->epoch = st->tiles2 = st->bar1 = st->bar2 = 0;
+  if (st->x1) {
+    /* group 1 = the row group (p2 members; the whole world on a 1 x p mesh).  Slots: READY and FREE per ring slot (the slab
+     * schedule has one "slot", its receive volume), then one barrier slot for the mirrored inverse */
+    const int ring = st->slab_zyx ? 1 : st->ring;
+    if (p2p_group_open(st, &st->g1, 1, p2, ry, 2 * ring + 1)) return -1;
+    st->use1 = (unsigned long long *)calloc((size_t)ring, sizeof(unsigned long long));
+    st->peer_r1 = (void **)calloc((size_t)p2, sizeof(void *));
+    if (!st->use1 || !st->peer_r1) return -1;
+    if (st->slab_zyx) {
+      const size_t bytes = st->sblkS * p2 * st->sNt * st->esz;
+      if (be->peer_open(st, 1, p2, ry, st->R1, bytes, st->peer_r1)) return -1;
+      st->tab_p1 = st->slab_yc ? tab_peers(st, p2, st->sH, (long long)c->M2 * st->sTz * st->sT * st->sNt, ry, st->peer_r1, st->R1)
+                               : tab_peers(st, p2, 1, (long long)st->sblkS, ry, st->peer_r1, st->R1);
+      if (!st->tab_p1) return -1;
+    } else {
+      const size_t slot = ((st->blk1 * p2 * st->esz + 255) / 256) * 256;
+      if (be->peer_open(st, 1, p2, ry, st->recv1_base, slot * (size_t)st->ring, st->peer_r1)) return -1;
+      st->tab_pr = (long long **)calloc((size_t)st->ring, sizeof(long long *));
+      if (!st->tab_pr) return -1;
+      for (int r = 0; r < st->ring; r++) {
+        void *pr[p2];
+        for (int a = 0; a < p2; a++) pr[a] = (char *)st->peer_r1[a] + (size_t)r * slot;
+        st->tab_pr[r] = tab_peers(st, p2, 1, (long long)st->blk1, ry, pr, st->recv1[r]);
+        if (!st->tab_pr[r]) return -1;
+      }
+    }
+  }
+  if (st->x2) {
+    /* group 2 = the column group (p1 members).  Slots: READY (tiles sent so far), FREE (transforms consumed), barrier */
+    if (p2p_group_open(st, &st->g2, 2, p1, rx, 3)) return -1;
+    st->peer_x2 = (void **)calloc((size_t)p1, sizeof(void *));
+    if (!st->peer_x2) return -1;
+    if (be->peer_open(st, 2, p1, rx, st->recv2, st->blk2 * p1 * st->esz, st->peer_x2)) return -1;
+    const long long stride = st->pencil_yc ? (long long)st->ntiles * st->H2 * ((long long)st->Tz2 * c->M4 * st->T) : (long long)st->blk2;
+    st->tab_p2 = tab_peers(st, p1, 1, stride, rx, st->peer_x2, st->recv2);
+    if (!st->tab_p2) return -1;
+  }
   return 0;
 }
 
@@ -735,6 +992,7 @@ static void state_free(hip_state *st) {
   if (!st) return;
   const offt_backend *be = st->be;
   be->dfree(st->work);
+  be->dfree(st->agree_d); free(st->agree_h);
   mesh_teardown(st);
   be->dfree(st->stage);
   be->event_destroy(st->ev0); be->event_destroy(st->ev1);
@@ -789,6 +1047,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->out_scale = 1.0;
   st->self_bypass = !(getenv("OFFT_SELF_BYPASS") && atoi(getenv("OFFT_SELF_BYPASS")) == 0);
   st->k1_streams = getenv("OFFT_K1_STREAMS") ? atoi(getenv("OFFT_K1_STREAMS")) : 1;
+  st->want_p2p = getenv("OFFT_EXCHANGE") && !strcmp(getenv("OFFT_EXCHANGE"), "p2p");
   /* scratch planes are offset by an odd number of 128-B lines (9 = 1152 B) so that the x-planes a
    * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt).  In
    * elements that is 72 for double and 144 for single precision: the 72 single-precision elements of r01
@@ -850,9 +1109,30 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     st->s_comm1 = be->stream_create();
     st->s_comm2 = (getenv("OFFT_COMM_STREAMS") && atoi(getenv("OFFT_COMM_STREAMS")) >= 2) ? be->stream_create() : st->s_comm1;
     if (!st->s_comm1 || !st->s_comm2) goto fail;
-    if (mesh_setup(po, st)) goto fail;
+    if (po->p > 1) {
+      st->agree_d = (double *)be->dmalloc(sizeof(double) * 2 * (size_t)po->p);
+      st->agree_h = (double *)malloc(sizeof(double) * 2 * (size_t)po->p);
+      if (!st->agree_d || !st->agree_h) goto fail;
+    }
+    {
+      /* every rank learns whether EVERY rank could build the plan (a max over the world of the local result): a rank
+       * that ran out of memory must not leave the others waiting in the first exchange */
+      double bad = mesh_setup(po, st) ? 1.0 : 0.0;
+      const int mine = bad > 0.0;
+      if (world_max(po, &bad) || bad > 0.0) {
+        if (!mine) SET_ERR("offt_3d_init: another rank could not build the plan");
+        goto fail;
+      }
+    }
   }
   po->t_init[INIT_BUFFER] = wall_seconds() - tb0;
+  if (st->use_pipeline && !st->slab_zyx && custom_params && custom_params->v[_W2_] > 0 && !po->rank) {
+    /* the reference keeps W2 tiles of phase 2 in flight (offt-compute.c:3682-3862); here exchange 2 streams behind
+     * exchange 1 into a full receive volume and FFTx follows chunk by chunk, so only W2 == 0 (wait for the whole
+     * exchange, the reference's blocking mode) differs from any other value */
+    printf("offt(hip): W2=%d: only W2 == 0 (blocking) vs W2 != 0 (FFTx overlapped with exchange 2) matters here; the window depth has no effect\n",
+           custom_params->v[_W2_]);
+  }
   if (max_loop > 0) static_sweep(po, out, custom_params);
   po->t_init[INIT_ALL] = wall_seconds() - t0;
   if (!po->rank) { /* offt-compute.c:3469-3471 */
@@ -912,14 +1192,15 @@ static void db_append(const char *path, const int *v, double perf) {
  * then contributes a large value), so that no rank is left alone inside an exchange.  It is an all-to-all of 8 bytes on
  * the world group through the backend's own exchange (which = 0: peer index == world rank), so it works over RCCL,
  * over the shared-GPU test transport and on the CPU test backend alike.  0 on success. */
+static int wait_compute_ex(hip_state *st, int watch);
 static int world_max(struct _offt_plan *po, double *v) {
   hip_state *st = (hip_state *)po->hip_state;
   const offt_backend *be = st->be;
   const int p = po->p;
   if (p == 1) return 0;
   TEST_NOTE_MESH(po);
-  double *d = (double *)be->dmalloc(sizeof(double) * 2 * (size_t)p), *h = (double *)malloc(sizeof(double) * 2 * (size_t)p);
-  if (!d || !h) { be->dfree(d); free(h); return -1; }
+  double *d = st->agree_d, *h = st->agree_h;
+  if (!d || !h) { *v = 99999999.0; return -1; }
   for (int a = 0; a < p; a++) { h[a] = *v; h[p + a] = 0; }
   const void *sp[p]; void *rp[p]; size_t sb[p], rb[p]; int pr[p];
   for (int a = 0; a < p; a++) { pr[a] = a; sp[a] = d + a; rp[a] = d + p + a; sb[a] = rb[a] = sizeof(double); }
@@ -927,13 +1208,13 @@ static int world_max(struct _offt_plan *po, double *v) {
   if (g_backend) memcpy(d, h, sizeof(double) * 2 * p);
   else if (hipMemcpy(d, h, sizeof(double) * 2 * p, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
   if (!rc) rc = be->a2a(st, 0, p, pr, sp, sb, rp, rb, st->s_compute);
-  if (!rc) rc = be->stream_sync(st->s_compute);
+  /* bounded and error-polling like the end of an execute: a rank that never joins must not hang the others for ever */
+  if (!rc) rc = wait_compute_ex(st, !g_backend && !g_test_transport && G.have_comm);
   if (!rc) {
     if (g_backend) memcpy(h, d, sizeof(double) * 2 * p);
     else if (hipMemcpy(h, d, sizeof(double) * 2 * p, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
   }
   if (!rc) for (int a = 0; a < p; a++) if (h[p + a] > *v) *v = h[p + a];
-  be->dfree(d); free(h);
   if (rc) *v = 99999999.0;
   return rc;
 }
@@ -1046,20 +1327,30 @@ static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _of
     for (int ax = 0; ax < 3; ax++) st->variant[ax] = best_variant;
     memcpy(v, best_v, sizeof best_v);
   } else {
-    /* ---- stage A: mesh shape P1 in {1, the default divisor <= sqrt(p), p} (offt-compute.c:3002-3023 is the lattice the
-     * tuner searches, offt-tuning.c:879-992 rebuilds communicator, buffers and plans per point like mesh_rebuild) ---- */
-    int cand[3], nc = 0;
+    /* ---- stage A: mesh shape.  Every P1 of the reference's lattice -- the divisors of p within
+     * [max(p/Nz', p/Ny, 1), min(Nx, Ny, p)], offt-compute.c:3002-3023 -- is a candidate, as for the tuner
+     * (offt-tuning.c:879-992 rebuilds communicator, buffers and plans per point like mesh_rebuild); the order is the
+     * default, the two slab shapes 1 and p, then the remaining divisors, so that a small max_loop still sees the
+     * shapes that differ most ---- */
+    enum { MAXC = 64 };
+    int cand[MAXC], nc = 0;
     const int p1_now = v[_P1_];
     if (custom && custom->v[_P1_] >= 0) cand[nc++] = p1_now; /* the caller fixed the mesh (-d) */
     else {
-      const int want[3] = {p1_now, 1, po->p};
-      for (int i = 0; i < 3; i++) {
+      int want[MAXC], nw = 0;
+      want[nw++] = p1_now; want[nw++] = 1; want[nw++] = po->p;
+      for (int d = 2; d < po->p && nw < MAXC; d++) if (po->p % d == 0) want[nw++] = d;
+      for (int i = 0; i < nw && nc < MAXC; i++) {
         int dup = 0;
         for (int j = 0; j < nc; j++) dup |= cand[j] == want[i];
         if (!dup && p1_feasible(po, want[i])) cand[nc++] = want[i];
       }
       if (!nc) cand[nc++] = p1_now;
     }
+    /* the tiling every candidate starts from: the caller's / default T1 and T2, not the merged values of the mesh
+     * tried before it (each mesh merges them upwards for its own message sizes) */
+    const int T1_0 = v[_T1_], T2_0 = v[_T2_];
+    int candT[MAXC], candTz[MAXC];
     /* the scratch array must hold the local volume of every mesh tried (run-fft.c:270-288 sizes its array the same way) */
     size_t need = local_elems(po->comm);
     for (int i = 0; i < nc; i++) {
@@ -1074,20 +1365,26 @@ static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _of
     own = 1;
     int rc_buf = buf ? 0 : -1;
     if (buf && !g_backend) (void)hipMemset(buf, 0, need * st->esz);
-    int best_p1 = p1_now;
+    int best_p1 = p1_now, best_i = 0;
     for (int i = 0; i < nc && points < po->max_loop; i++, points++) {
       int rc = rc_buf;
+      v[_T1_] = T1_0; v[_T2_] = T2_0;
       if (cand[i] != v[_P1_] && mesh_rebuild(po, cand[i])) rc = -1;
       if (st->slab_zyx) { v[_T1_] = st->sT; v[_T2_] = st->sTz; } else { v[_T1_] = st->T; v[_T2_] = st->Tz2; }
+      candT[i] = v[_T1_]; candTz[i] = v[_T2_]; /* the tiling this mesh was timed with */
       const double perf = sweep_time_point(po, buf, rc);
       sweep_report(po, perf);
-      if (perf < best) { best = perf; best_p1 = cand[i]; }
+      if (perf < best) { best = perf; best_p1 = cand[i]; best_i = i; }
     }
+    /* back to the winner, with exactly the tiling it was timed with (as fixed values: `best` belongs to that point) */
     int rc_mesh = 0;
-    if (best_p1 != v[_P1_]) rc_mesh = mesh_rebuild(po, best_p1);
-    /* ---- stage B: tiling at that mesh.  slab: x-tile thickness T1 (message granularity of the exchange) x z-chunk
-     * thickness T2 (granularity of the overlapped FFTy/FFTx work); pencil: T1 x W1, then T2 -- around the defaults ---- */
     st->t1_custom = st->t2_custom = 1;
+    v[_T1_] = candT[best_i]; v[_T2_] = candTz[best_i];
+    if (best_p1 != v[_P1_]) rc_mesh = mesh_rebuild(po, best_p1);
+    else if (st->slab_zyx) { slab_teardown(st); rc_mesh = slab_setup(po, st); }
+    else { ring_teardown(st); rc_mesh = ring_setup(po, st); }
+    /* ---- stage B: tiling at that mesh.  slab: x-tile thickness T1 (message granularity of the exchange) x z-chunk
+     * thickness T2 (granularity of the overlapped FFTy/FFTx work); pencil: T1 x W1, then T2 -- around the winner ---- */
     const int M1 = po->comm->M1, M3 = po->comm->M3;
     if (st->slab_zyx) { v[_T1_] = st->sT; v[_T2_] = st->sTz; } else { v[_T1_] = st->T; v[_T2_] = st->Tz2; }
     memcpy(best_v, v, sizeof best_v);
@@ -1165,6 +1462,21 @@ void offt_hip_set_stream(struct _offt_plan *po, void *stream) {
   if (stream) { st->s_compute = stream; st->own_stream = 0; }
   else { st->s_compute = st->be->stream_create(); st->own_stream = 1; }
 }
+/* exchange of a multi-rank plan: OFFT_HIP_EXCHANGE_STAGED (packed send volume + grouped RCCL send/recv, the default) or
+ * OFFT_HIP_EXCHANGE_DIRECT (the packing passes store straight into the peers' receive volumes).  Collective: every rank
+ * of the world calls it with the same mode; buffers and mappings are rebuilt.  Returns the mode now in use (direct falls
+ * back to staged, on all ranks together, where peer memory cannot be mapped), or -1. */
+int offt_hip_set_exchange(struct _offt_plan *po, int mode) {
+  hip_state *st = (hip_state *)po->hip_state;
+  if (!st->use_pipeline) return OFFT_HIP_EXCHANGE_STAGED;
+  if (st->be->stream_sync(st->s_compute)) return -1;
+  mesh_teardown(st);
+  st->want_p2p = mode == OFFT_HIP_EXCHANGE_DIRECT;
+  double bad = mesh_setup(po, st) ? 1.0 : 0.0;
+  if (world_max(po, &bad) || bad > 0.0) { SET_ERR("offt_hip_set_exchange: a rank could not rebuild its buffers"); return -1; }
+  return st->p2p ? OFFT_HIP_EXCHANGE_DIRECT : OFFT_HIP_EXCHANGE_STAGED;
+}
+int offt_hip_get_exchange(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->p2p ? OFFT_HIP_EXCHANGE_DIRECT : OFFT_HIP_EXCHANGE_STAGED; }
 void offt_hip_set_output_scale(struct _offt_plan *po, double scale) { ((hip_state *)po->hip_state)->out_scale = scale; }
 void offt_hip_set_async(struct _offt_plan *po, int async) { ((hip_state *)po->hip_state)->async = async; }
 void offt_hip_set_debug_skip(struct _offt_plan *po, int mask) { ((hip_state *)po->hip_state)->skip_mask = mask; }
@@ -1399,7 +1711,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
 /* order on the compute stream (no overlap tuning for this extension).         */
 /* ------------------------------------------------------------------------- */
 typedef struct step {
-  int kind;               /* 0 = pass, 1 = exchange */
+  int kind;               /* 0 = pass, 1 = exchange, 2 = a flag operation of the direct-store exchange on group `which` */
   int first;              /* pass reads the caller's input layout (K1): it writes the inverse's result */
   offt_pass_desc d; const void *src; void *dst;
   int which, cnt; int *peer; const void **sp; size_t *sb; void **rp; size_t *rb;
@@ -1438,6 +1750,27 @@ static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const voi
   return 0;
 }
 
+/* flag operations of the direct-store exchange.  Recorded (multi-rank inverse) they become plain sync points: the
+ * mirrored schedule puts a barrier of the group wherever the forward schedule signals or waits -- every dependency of the
+ * forward schedule crosses at least one of these points, so its mirror image is ordered by the barriers. */
+static int run_signal(hip_state *st, p2p_group *g, int slot, unsigned long long value, void *stream) {
+  if (st->skip_mask & 2) return 0;
+  if (st->rec) { step *e = rec_new(st->rec); e->kind = 2; e->which = g->which; return 0; }
+  return p2p_signal(st, g, slot, value, stream);
+}
+static int run_wait(hip_state *st, p2p_group *g, int slot, unsigned long long value, void *stream) {
+  if (st->skip_mask & 2) return 0;
+  if (st->rec) { step *e = rec_new(st->rec); e->kind = 2; e->which = g->which; return 0; }
+  return p2p_wait(st, g, slot, value, stream);
+}
+static int p2p_barrier(hip_state *st, int which, void *stream) {
+  p2p_group *g = which == 2 ? &st->g2 : &st->g1;
+  unsigned long long *bar = which == 2 ? &st->bar2 : &st->bar1;
+  const unsigned long long v = ++*bar;
+  if (p2p_signal(st, g, g->nslots - 1, v, stream)) return -1;
+  return p2p_wait(st, g, g->nslots - 1, v, stream);
+}
+
 static int execute_slab(struct _offt_plan *po, void *data);
 static int execute_pipeline(struct _offt_plan *po, void *data, int dir);
 
@@ -1464,6 +1797,10 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
       d.in_contig = f.out_contig; d.out_contig = f.in_contig;
       d.scale = e->first ? st->out_scale : 1.0;
       rc = be->pass(&d, e->dst, (void *)e->src, s);
+    } else if (e->kind == 2) {
+      /* one barrier per recorded flag operation, never merged: ranks with an empty tile record no pass between two
+       * operations where the others do, and every rank must run the same number of barriers */
+      rc = p2p_barrier(st, e->which, s);
     } else {
       rc = be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, s);
     }
@@ -1544,9 +1881,10 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->sblkS = (size_t)c->M3 * c->M2 * T;
   /* y-contiguous block layout (see execute_slab): needs even z blocks that are whole chunks */
   st->slab_yc = c->b3 == 0 && c->M3 % Tz == 0 && !(getenv("OFFT_SLAB_XC_LAYOUT") && atoi(getenv("OFFT_SLAB_XC_LAYOUT")));
-  st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
+  /* (direct-store exchange: no send volume -- K1 stores into the peers' R1, its own block into its own) */
+  if (!(st->p2p && st->x1)) st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
   st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
-  if (!st->S1 || !st->R2) return -1;
+  if ((!st->S1 && !(st->p2p && st->x1)) || !st->R2) return -1;
   if (st->x1) {
     st->R1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
     if (!st->R1) return -1;
@@ -1557,7 +1895,7 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   for (int h = 0; h < st->sH; h++) st->ev_sa[h] = be->event_create();
   /* the self block bypasses the exchange (see tab_self): K1 stores this rank's own z-block straight into R1.  In the
    * y-contiguous layout a peer's share is sH chunk blocks of the split, otherwise one block */
-  if (st->self_bypass && st->x1 && c->p2 > 1) {
+  if (st->self_bypass && st->x1 && c->p2 > 1 && !st->p2p) {
     int ok = 1;
     const long long delta = elem_delta(st, st->R1, st->S1, &ok);
     if (ok) st->tab_s1 = st->slab_yc ? tab_self(st, c->p2, st->sH, (long long)c->M2 * Tz * T * st->sNt, po->rank % c->p2, delta)
@@ -1576,6 +1914,12 @@ static int execute_slab(struct _offt_plan *po, void *data) {
   int peers[p2 > 0 ? p2 : 1];
   for (int a = 0; a < p2; a++) peers[a] = a;
   const int nfull = c->m1 / T, tail = c->m1 - nfull * T; /* full x-tiles and the ragged last one */
+  /* direct-store exchange: K1 stores every block into its owner's R1 (tab_p1), flags replace the exchange:
+   *   wait FREE(e-1) | K1(all tiles) | signal READY(e) | wait READY(e) | K2(h) K3(h) ... | signal FREE(e)              */
+  const int p2p = st->p2p && st->x1;
+  /* (a schedule that is only being RECORDED for the mirrored inverse issues no flag operation and must not count one) */
+  const unsigned long long ep = (p2p && !st->rec) ? ++st->epoch : 0;
+  if (p2p && run_wait(st, &st->g1, 1, ep - 1, s)) return -1;
 
   /* ---- K1: FFTz + pack (offt-compute.c:905-1206), all x-tiles ---- */
   be->event_record(st->evp[0], s);
@@ -1607,8 +1951,8 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.out_axis_stride = (long long)c->M2 * T; d.out_col_stride = 1; d.out_b1_stride = T;
         if (p2 > 1) { d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0; d.out_block_stride = (long long)st->sblkS; }
       }
-      d.out_block_tab = st->tab_s1; /* (relative to k1dst: the tile offset is the same in S1 and R1) */
-      char *k1dst = (char *)st->S1 + (st->slab_yc ? (size_t)i * c->M2 * Tz * T : (size_t)i * p2 * st->sblkS) * esz;
+      d.out_block_tab = p2p ? st->tab_p1 : st->tab_s1; /* (relative to k1dst: the tile offset is the same in S1 and every R1) */
+      char *k1dst = (char *)(p2p ? st->R1 : st->S1) + (st->slab_yc ? (size_t)i * c->M2 * Tz * T : (size_t)i * p2 * st->sblkS) * esz;
       if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, k1dst, sk, 1)) return -1;
     }
     be->event_record(st->ev_s1[i], sk);
@@ -1621,7 +1965,9 @@ static int execute_slab(struct _offt_plan *po, void *data) {
    * goes out as ONE grouped call (nt * p2 pieces).  With t_K1 the K1 phase and C the time on the
    * wire, chunk h lands at about t_K1(0) + (h+1) C/H and is needed at t_K1 + h (t_K2+t_K3)/H:
    * the wire is never idle and compute only waits if the links are the bottleneck. ---- */
-  if (st->x1) {
+  if (p2p) {
+    if (run_signal(st, &st->g1, 0, ep, s) || run_wait(st, &st->g1, 0, ep, s)) return -1;
+  } else if (st->x1) {
     for (int h = 0; h < H; h++) {
       const int z0 = h * Tz;
       int tz = c->M3 - z0; if (tz > Tz) tz = Tz;
@@ -1657,7 +2003,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     const int z0 = h * Tz;
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
-    if (st->x1) be->stream_wait(s, st->ev_sa[h]);
+    if (st->x1 && !p2p) be->stream_wait(s, st->ev_sa[h]);
     /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
     if (nz > 0) {
       const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (st->slab_yc ? (size_t)h * nt * c->M2 * Tz * T : (size_t)z0 * c->M2 * T) * esz;
@@ -1694,6 +2040,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       if (run_pass(st, &d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
     }
   }
+  if (p2p && run_signal(st, &st->g1, 1, ep, s)) return -1; /* R1 is consumed: the peers may store the next transform */
   be->event_record(st->evp[2], s);
   be->event_record(st->evp[3], s);
   return 0;
@@ -1739,6 +2086,11 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
   for (int a = 0; a < p1; a++) peers2[a] = a; /* key = rank_x inside comm2 */
   const int Hf = c->m3 / Tz;                   /* chunks whose Tz planes are all owned by this rank */
   const int w2 = po->params->v[_W2_];
+  /* direct-store exchange: K1 stores into the row peers' ring slots (tab_pr[r]), K2 into the column peers' recv2 (tab_p2):
+   *   per tile  wait FREE1[r] | K1 | signal READY1[r] ... wait READY1[r] | K2 | signal FREE1[r], signal READY2
+   *   then      wait READY2 (all tiles) | K3(h) ... | signal FREE2                                                    */
+  const int pp1 = st->p2p && st->x1, pp2 = st->p2p && st->x2;
+  const unsigned long long ep = (st->p2p && !st->rec) ? ++st->epoch : 0; /* (recording for the mirrored inverse: no flags, no counting) */
 
   /* One in-order compute stream carries the reference's software pipeline
    * "pack(i); wait(i-W); ia2a(i); unpack(i-W)" (offt-compute.c:3537-3647): K1(i) then
@@ -1752,6 +2104,10 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const int r = i % st->ring, x0 = i * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
       if (i >= st->ring) be->stream_wait(s, st->ev_k2[r]); /* slot's previous tile fully consumed */
+      if (pp1) { /* ... by every row peer: they read what this rank stored into THEIR slot r */
+        if (run_wait(st, &st->g1, st->ring + r, st->use1[r], s)) return -1;
+        if (!st->rec) st->use1[r]++;
+      }
       if (myT > 0 && c->m2 > 0) {
         offt_pass_desc d;
         desc_init(&d, st, Nz, dir, 2);
@@ -1770,12 +2126,15 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
           d.out_split = c->F3; d.out_split_nfloor = c->b3 ? p2 - c->b3 : 0;
           d.out_block_stride = (long long)st->blk1;
           if (st->tab_r1) d.out_block_tab = st->tab_r1[r];
+          if (pp1) d.out_block_tab = st->tab_pr[r];
         }
         if (run_pass(st, &d, (char *)data + (size_t)x0 * c->istride[0] * esz, st->send1[r], s, 1)) return -1;
       }
       be->event_record(st->ev_k1[r], s);
       /* ---- a2a1(i) over comm1 (offt-compute.c:862-881) ---- */
-      if (st->x1) {
+      if (pp1) {
+        if (run_signal(st, &st->g1, r, st->use1[r], s)) return -1;
+      } else if (st->x1) {
         be->stream_wait(st->s_comm1, st->ev_k1[r]);
         const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2]; int pr[p2], cnt = 0;
         for (int a = 0; a < p2; a++) {
@@ -1795,7 +2154,9 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- K2(k): unpack1 + FFTy (+ pack2) (offt-compute.c:1208-1520, 1636-2345) ---- */
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
-      if (st->x1) be->stream_wait(s, st->ev_a1[r]);
+      if (pp1) { if (run_wait(st, &st->g1, r, st->use1[r], s)) return -1; }
+      else if (st->x1) be->stream_wait(s, st->ev_a1[r]);
+      if (pp2 && k == 0 && run_wait(st, &st->g2, 1, ep - 1, s)) return -1; /* the column peers have consumed the previous transform's recv2 */
       if (st->pencil_yc && myT > 0) {
         /* whole y-lines out of the receive blocks [x_t][z_l][y_l] (runs of F2 per peer), columns = x_t, into the
          * column-exchange volume [chunk][peer][x-tile][z in chunk][y_l][x_t]: x contiguous, one (chunk, peer, tile)
@@ -1815,7 +2176,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
           d.out_block_stride = (long long)st->ntiles * H * B2;
-          d.out_block_tab = st->tab_x2; /* (relative to the launch pointer: tile / chunk offsets are the same in send2 and recv2) */
+          d.out_block_tab = pp2 ? st->tab_p2 : st->tab_x2; /* (relative to the launch pointer: tile / chunk offsets are the same in send2 and every recv2) */
         }
         if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * H * B2 * esz, s, 0)) return -1;
       }
@@ -1840,16 +2201,18 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
           d.out_block_stride = (long long)st->blk2;
-          d.out_block_tab = st->tab_x2;
+          d.out_block_tab = pp2 ? st->tab_p2 : st->tab_x2;
         }
         if (run_pass(st, &d, (char *)st->recv1[r] + (size_t)z0 * esz,
                      (char *)st->send2 + ((size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz, s, 0)) return -1;
       }
       be->event_record(st->ev_k2[r], s);
+      if (pp1 && run_signal(st, &st->g1, st->ring + r, st->use1[r], s)) return -1; /* slot r consumed */
+      if (pp2 && run_signal(st, &st->g2, 0, st->rec ? 0 : ++st->tiles2, s)) return -1; /* tile k is in the column peers' recv2 */
       /* ---- a2a2(k) over comm2: x-tile k of every z-chunk of every column block.  All chunks of a tile go in one
        * grouped call, except for the last tile: there each chunk is its own call with an event behind it, so that
        * K3(h) can start while chunks h+1.. are still on the wire ---- */
-      if (st->x2) {
+      if (st->x2 && !pp2) {
         be->stream_wait(st->s_comm2, st->ev_k2[r]);
         const int last = (k == st->ntiles - 1);
         const int merged = st->pencil_yc && !last; /* one contiguous message per peer holds every chunk of the tile */
@@ -1884,12 +2247,13 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     }
   }
   be->event_record(st->evp[2], s);
+  if (pp2 && run_wait(st, &st->g2, 0, st->tiles2, s)) return -1; /* every column peer has stored all its tiles (they count like this rank) */
   /* ---- K3(h): unpack2 + FFTx into the caller's layout (offt-compute.c:2347-2993), z-chunk by z-chunk ---- */
   for (int h = 0; h < H; h++) {
     const int z0 = h * Tz;
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh;
-    if (st->x2) be->stream_wait(s, st->ev_a2[w2 == 0 ? H - 1 : h]);
+    if (st->x2 && !pp2) be->stream_wait(s, st->ev_a2[w2 == 0 ? H - 1 : h]);
     if (nz <= 0 || c->m4 <= 0) continue;
     offt_pass_desc d;
     desc_init(&d, st, Nx, dir, 0);
@@ -1916,6 +2280,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     d.out_col_stride = c->ostride[2]; d.out_b1_stride = c->ostride[1];
     if (run_pass(st, &d, (char *)st->recv2 + (size_t)z0 * MM * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
   }
+  if (pp2 && run_signal(st, &st->g2, 1, ep, s)) return -1; /* recv2 is consumed */
   be->event_record(st->evp[3], s);
   return 0;
 }
@@ -1929,11 +2294,15 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
 static void comm_fail(hip_state *st) {
   G.comm_failed = 1;
   if (R.CommAbort) {
-    if (st->have_comm1) { (void)R.CommAbort(st->comm1); st->have_comm1 = 0; }
-    if (st->have_comm2) { (void)R.CommAbort(st->comm2); st->have_comm2 = 0; }
+    if (st->have_comm1) { (void)R.CommAbort(st->comm1); st->have_comm1 = 0; st->comm1 = NULL; }
+    if (st->have_comm2) { (void)R.CommAbort(st->comm2); st->have_comm2 = 0; st->comm2 = NULL; }
+    if (st->comm1 == G.world) st->comm1 = NULL; /* a group that spans the world uses the world communicator itself */
+    if (st->comm2 == G.world) st->comm2 = NULL;
     if (G.have_comm) { (void)R.CommAbort(G.world); G.have_comm = 0; G.world = NULL; }
   }
-  st->comm1 = st->comm2 = NULL;
+  /* an RCCL without ncclCommAbort: the communicators stay as they are -- their kernels may still be spinning, so they
+   * are neither destroyed (ncclCommDestroy would block) nor forgotten; G.comm_failed makes every later call fail fast
+   * and mesh_teardown / offt_hip_finalize_world skip them (a documented leak, the process is expected to exit) */
 }
 
 static int comm_async_error(hip_state *st) {
@@ -1953,8 +2322,8 @@ static int comm_async_error(hip_state *st) {
 /* wait for the compute stream.  A plan that exchanges over RCCL polls instead of blocking: every millisecond the
  * communicators are asked for asynchronous errors, and the wait is bounded (OFFT_EXEC_TIMEOUT seconds, default 120) --
  * a dead or stuck peer becomes the failure marker t[ALL] = 99999999 plus offt_hip_last_error(), not a hang. */
-static int wait_compute(hip_state *st) {
-  if (!st->uses_rccl) return st->be->stream_sync(st->s_compute);
+static int wait_compute_ex(hip_state *st, int watch) {
+  if (!watch) return st->be->stream_sync(st->s_compute);
   const double limit = getenv("OFFT_EXEC_TIMEOUT") ? atof(getenv("OFFT_EXEC_TIMEOUT")) : 120.0;
   const double t0 = wall_seconds();
   double tchk = t0;
@@ -1975,6 +2344,16 @@ static int wait_compute(hip_state *st) {
   if (comm_async_error(st)) { comm_fail(st); return -1; }
   return 0;
 }
+static int wait_compute(hip_state *st) {
+  const int rc = wait_compute_ex(st, st->uses_rccl);
+  if (!rc && st->p2p && st->p2p_status && *(volatile unsigned long long *)st->p2p_status) {
+    /* a wait kernel of the direct-store exchange ran out of time: a peer never signalled */
+    SET_ERR("offt_3d_execute: a flag of the direct-store exchange did not arrive (a peer is missing or stuck)");
+    G.comm_failed = 1;
+    return -1;
+  }
+  return rc;
+}
 
 void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int direction) {
   hip_state *st = (hip_state *)po->hip_state;
@@ -1987,7 +2366,7 @@ void offt_3d_execute_dir(struct _offt_plan *po, void *in, void *out, int directi
     fprintf(stderr, "offt(hip): offt_3d_execute is in-place; `in` is ignored (as in the reference)\n");
     st->warned_in = 1;
   }
-  if (st->uses_rccl && G.comm_failed) {
+  if ((st->uses_rccl || st->p2p) && G.comm_failed) {
     SET_ERR("offt_3d_execute: the communicator failed earlier; make a new world (offt_hip_set_world) and plan");
     t[ALL] = 99999999.0;
     return;
@@ -2110,36 +2489,56 @@ double offt_hip_link_probe(int mode, int shift, long long bytes, int reps) {
     SET_ERR("offt_hip_link_probe: allocation failed");
     goto done;
   }
-  for (int r = -1; r < reps; r++) { /* r = -1: warm-up (connection set-up), not timed */
+  int broken = 0; /* an exchange was enqueued and may never finish: the communicator is aborted before anything is freed */
+  for (int r = -1; r < reps && !broken; r++) { /* r = -1: warm-up (connection set-up), not timed */
     if (r == 0 && hipEventRecord(e0, s) != hipSuccess) goto done;
     NCHECK(R.GroupStart(), goto done);
+    int grc = 0;
     if (mode == 0) {
-      for (int a = 0; a < p; a++) {
+      for (int a = 0; a < p && !grc; a++) {
         if (a == me) continue;
-        NCHECK(R.Send(sbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), goto done);
-        NCHECK(R.Recv(rbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), goto done);
+        NCHECK(R.Send(sbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), grc = -1);
+        if (!grc) NCHECK(R.Recv(rbuf + (size_t)a * bytes, (size_t)bytes, NCCL_INT8, a, G.world, s), grc = -1);
       }
     } else {
       const int to = (me + shift % p + p) % p, from = (me - shift % p + p) % p;
       if (to != me) {
-        NCHECK(R.Send(sbuf, (size_t)bytes, NCCL_INT8, to, G.world, s), goto done);
-        NCHECK(R.Recv(rbuf, (size_t)bytes, NCCL_INT8, from, G.world, s), goto done);
+        NCHECK(R.Send(sbuf, (size_t)bytes, NCCL_INT8, to, G.world, s), grc = -1);
+        if (!grc) NCHECK(R.Recv(rbuf, (size_t)bytes, NCCL_INT8, from, G.world, s), grc = -1);
       }
     }
-    NCHECK(R.GroupEnd(), goto done);
+    if (grc) { (void)R.GroupEnd(); broken = 1; break; } /* never leave a group open behind a failed call (as hb_a2a) */
+    NCHECK(R.GroupEnd(), { broken = 1; break; });
   }
-  if (hipEventRecord(e1, s) != hipSuccess) goto done;
-  {
-    /* bounded wait, like an execute */
+  if (!broken && hipEventRecord(e1, s) != hipSuccess) broken = 1;
+  if (!broken) {
+    /* bounded, error-polling wait, like the end of an execute */
     const double t0 = wall_seconds();
+    double tchk = t0;
     for (;;) {
       const hipError_t q = hipStreamQuery(s);
       if (q == hipSuccess) break;
-      if (q != hipErrorNotReady || wall_seconds() - t0 > 60.0) { SET_ERR("offt_hip_link_probe: exchange did not complete"); goto done; }
+      const double now = wall_seconds();
+      if (q != hipErrorNotReady || now - t0 > 60.0) { SET_ERR("offt_hip_link_probe: exchange did not complete"); broken = 1; break; }
+      if (now - tchk < 1e-3) continue;
+      tchk = now;
+      if (R.CommGetAsyncError) {
+        ncclResult_t ar = 0;
+        if (R.CommGetAsyncError(G.world, &ar) != 0 || (ar != 0 && ar != NCCL_IN_PROGRESS)) {
+          SET_ERR("offt_hip_link_probe: RCCL reported an asynchronous error: %s", R.GetErrorString(ar));
+          broken = 1; break;
+        }
+      }
     }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) goto done;
-    result = 1e-3 * ms / reps;
+    if (!broken && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) result = 1e-3 * ms / reps;
+  }
+  if (broken) {
+    /* RCCL kernels may still be using the buffers: abort the communicator first (hipFree synchronises the device and
+     * would turn the time-out into a hang), and make every later execute on this world fail fast */
+    G.comm_failed = 1;
+    if (R.CommAbort) { (void)R.CommAbort(G.world); G.have_comm = 0; G.world = NULL; }
+    else { sbuf = rbuf = NULL; s = NULL; } /* no abort available: leak the buffers and the stream rather than block */
   }
 done:
   if (e0) (void)hipEventDestroy(e0);

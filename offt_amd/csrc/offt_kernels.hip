@@ -1020,6 +1020,59 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   return 0;
 }
 
+// ---- flags of the direct-store exchange (offt_hipk.h) ----
+namespace {
+struct FlagArgs {
+  unsigned long long *addr[OFFT_HIPK_MAX_FLAGS];
+  int n;
+  unsigned long long value;
+  unsigned long long *status;
+  long long timeout_ticks;  // of the 100 MHz constant clock (wall_clock64)
+};
+__global__ void __launch_bounds__(64) flag_signal_k(FlagArgs a) {
+  const int i = threadIdx.x;
+  // system scope: the word lives in a peer's memory (another GPU over xGMI, or another process's buffer on this one)
+  if (i < a.n) __hip_atomic_store(a.addr[i], a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(64) flag_wait_k(FlagArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n) {
+    const long long t0 = wall_clock64();
+    // every lane polls its own word; the loop ends for every lane: the value arrives or the clock runs out
+    while (__hip_atomic_load(a.addr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.value) {
+      if (wall_clock64() - t0 > a.timeout_ticks) {
+        if (a.status) __hip_atomic_store(a.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope; the next kernel's start-of-kernel acquire does the rest
+}
+int flag_launch(bool wait, int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status, double timeout_s,
+                void *stream) {
+  if (n < 0 || n > OFFT_HIPK_MAX_FLAGS) { snprintf(g_err, sizeof g_err, "offt_hipk_flag_%s: %d words (at most %d)", wait ? "wait" : "signal", n, OFFT_HIPK_MAX_FLAGS); return -1; }
+  if (n == 0) return 0;
+  FlagArgs a;
+  for (int i = 0; i < OFFT_HIPK_MAX_FLAGS; i++) a.addr[i] = i < n ? addr[i] : nullptr;
+  a.n = n; a.value = value; a.status = status;
+  a.timeout_ticks = (long long)(timeout_s * 1e8);
+  (void)hipGetLastError();
+  if (wait) hipLaunchKernelGGL(flag_wait_k, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(flag_signal_k, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  HIPK_CHECK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int offt_hipk_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream) {
+  return flag_launch(false, n, addr, value, nullptr, 0.0, stream);
+}
+int offt_hipk_flag_wait(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status, double timeout_s,
+                        void *stream) {
+  return flag_launch(true, n, addr, value, status, timeout_s, stream);
+}
+
 int offt_hipk_copy3d(const void *in, void *out, int precision, int n0, int n1, int n2, long long is0,
                      long long is1, long long is2, long long os0, long long os1, long long os2, void *stream) {
   long long total = (long long)n0 * n1 * n2;

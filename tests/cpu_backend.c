@@ -19,7 +19,12 @@ typedef int (*a2a_cb_t)(int which, int npeers, const int *peer, const void *cons
 static a2a_cb_t g_a2a_cb = NULL;
 static long g_pass_count = 0;
 
-static void *cb_malloc(size_t b) { return calloc(1, b ? b : 16); }
+/* failure injection: the n-th allocation from now fails once (an out-of-memory on ONE rank, tests/test_host_logic.py) */
+static long g_alloc_count = 0, g_fail_alloc_at = -1;
+static void *cb_malloc(size_t b) {
+  if (++g_alloc_count == g_fail_alloc_at) { g_fail_alloc_at = -1; return NULL; }
+  return calloc(1, b ? b : 16);
+}
 static void cb_free(void *p) { free(p); }
 static int cb_prepare(int n, int prec) { (void)n; (void)prec; return 0; }
 
@@ -86,12 +91,49 @@ static int cb_memcpy_dd(void *dst, const void *src, size_t bytes, void *s) { (vo
 
 static int cb_upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 
+/* direct-store exchange on host memory: several ranks as THREADS of one process see each other's buffers anyway; the
+ * test hands the pointers round through a callback (ranks as processes have no shared memory: -1, the library then falls
+ * back to the staged exchange).  Flags are plain atomics; a wait spins -- the passes run synchronously, so a rank really
+ * blocks here until its peers have stored and signalled. */
+typedef int (*peer_cb_t)(int which, int npeers, int self, void *local, size_t bytes, void **peers);
+static peer_cb_t g_peer_cb = NULL;
+static int cb_peer_open(void *ctx, int which, int npeers, int self, void *local, size_t bytes, void **peers) {
+  (void)ctx;
+  if (!g_peer_cb) return -1;
+  return g_peer_cb(which, npeers, self, local, bytes, peers);
+}
+static void cb_peer_close(void *ctx, int npeers, int self, void **peers) { (void)ctx; (void)npeers; (void)self; (void)peers; }
+static void *cb_flag_alloc(size_t bytes, int host_visible) { (void)host_visible; return calloc(1, bytes); }
+static void cb_flag_free(void *p, int host_visible) { (void)host_visible; free(p); }
+static int cb_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream) {
+  (void)stream;
+  for (int i = 0; i < n; i++) __atomic_store_n(addr[i], value, __ATOMIC_RELEASE);
+  return 0;
+}
+static int cb_flag_wait(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status, double timeout_s, void *stream) {
+  (void)stream;
+  struct timespec t0, t;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < n; i++)
+    while (__atomic_load_n(addr[i], __ATOMIC_ACQUIRE) < value) {
+      clock_gettime(CLOCK_MONOTONIC, &t);
+      if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s) { if (status) *status = 1; return 0; }
+      struct timespec nap = {0, 50000};
+      nanosleep(&nap, NULL);
+    }
+  return 0;
+}
+
 static const offt_backend k_cpu_backend = {cb_malloc, cb_free, cb_prepare, cb_pass, cb_stream_create, cb_stream_destroy,
                                            cb_event_create, cb_event_destroy, cb_event_record, cb_stream_wait,
-                                           cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd, cb_upload};
+                                           cb_stream_sync, cb_event_ms, cb_a2a, cb_memcpy_dd, cb_upload,
+                                           cb_peer_open, cb_peer_close, cb_flag_alloc, cb_flag_free, cb_flag_signal, cb_flag_wait};
 
 const offt_backend *cpu_backend_table(void) { return &k_cpu_backend; }
 /* run one descriptor on host arrays (descriptor-level parity tests against the HIP kernels) */
 int cpu_backend_run_pass(const offt_pass_desc *d, const void *in, void *out) { return cb_pass(d, in, out, NULL); }
 void cpu_backend_set_a2a(a2a_cb_t cb) { g_a2a_cb = cb; }
+void cpu_backend_set_peer_open(peer_cb_t cb) { g_peer_cb = cb; }
 long cpu_backend_pass_count(void) { return g_pass_count; }
+long cpu_backend_alloc_count(void) { return g_alloc_count; }
+void cpu_backend_fail_alloc_at(long n_from_now) { g_fail_alloc_at = n_from_now > 0 ? g_alloc_count + n_from_now : -1; }

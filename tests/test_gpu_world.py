@@ -51,7 +51,7 @@ def run_world(size, cases, tmp_path):
 
 def run_thread_world(size, cases, tmp_path):
     """`size` ranks as threads of ONE process on the one GPU (the box admits at most 6 processes on the card)"""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_thread_world.py"), str(size), json.dumps(cases), str(tmp_path)],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_thread_world.py"), str(size), json.dumps(cases), str(tmp_path)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-4000:]
     summary = json.load(open(tmp_path / "summary.json"))

@@ -279,6 +279,36 @@ def test_gloo_world4_static_sweep_with_mesh(built, tmp_path):
     assert {int(ln.split()[1]) for ln in open(tmp_path / "sweep2.db").read().splitlines()} == {2}
 
 
+def test_gloo_world8_sweep_covers_the_whole_p1_lattice(built, tmp_path):
+    """stage A of the static sweep enumerates every P1 the reference's lattice admits (offt-compute.c:3002-3023): on 8
+    ranks and 16^3 that is 1, 2, 4 and 8 -- four mesh points, identical choices on all ranks"""
+    cases = [dict(N=[16, 16, 16], params=dict(), max_loop=6, env=dict(OFFT_SWEEP_DB="{outdir}/sweep8.db", OFFT_MIN_MSG=0))]
+    _run_world(8, cases, tmp_path)
+    vs = [json.load(open(tmp_path / f"case0_rank{r}.json"))["v"] for r in range(8)]
+    assert all(v == vs[0] for v in vs), vs
+    lines = [ln.split() for ln in open(tmp_path / "sweep8.db").read().splitlines()]
+    assert len(lines) == 6
+    assert [int(ln[1]) for ln in lines[:4]] == [2, 1, 8, 4]                 # default first, the slab shapes, then the rest
+    assert len({int(ln[1]) for ln in lines[4:]}) == 1 and vs[0][0] == int(lines[4][1])
+    # the winner keeps the tiling it was timed with: its stage-A line reappears as the plan's final T1 / T2 unless stage B beat it
+    win = [ln for ln in lines[:4] if int(ln[1]) == vs[0][0]][0]
+    best_line = min(lines, key=lambda ln: float(ln[0]))
+    assert [int(x) for x in best_line[1:]] == vs[0] or float(best_line[0]) >= 99999999.0, (best_line, vs[0], win)
+
+
+def test_gloo_world4_one_rank_out_of_memory_during_the_sweep(built, tmp_path):
+    """a local failure (here: an allocation) on ONE rank while the sweep rebuilds the mesh must not leave the other ranks
+    alone in a collective: the point is marked infeasible by every rank (99999999, offt-compute.c:3881) and the sweep goes on"""
+    cases = [dict(N=[16, 16, 16], params=dict(), max_loop=5, fail_alloc=dict(rank=2),
+                  env=dict(OFFT_SWEEP_DB="{outdir}/sweep_oom.db", OFFT_MIN_MSG=0))]
+    _run_world(4, cases, tmp_path)
+    vs = [json.load(open(tmp_path / f"case0_rank{r}.json"))["v"] for r in range(4)]
+    assert all(v == vs[0] for v in vs), vs
+    lines = [ln.split() for ln in open(tmp_path / "sweep_oom.db").read().splitlines()]
+    assert float(lines[1][0]) >= 99999999.0 and float(lines[0][0]) < 99999999.0   # the second mesh point failed, for everybody
+    assert vs[0][0] != int(lines[1][1])                                           # ... and was not chosen
+
+
 def test_gloo_world8(built, tmp_path):
     """the 8-rank shapes the multi-GPU bench uses (1x8 slab, 2x4 pencil, 8x1), incl. r2c and ragged sizes"""
     cases = [dict(N=[16, 16, 16], params=dict(P1=1)), dict(N=[16, 16, 16], params=dict()),
