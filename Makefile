@@ -10,7 +10,7 @@ BUILD     := build
 HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -I$(BUILD)
 CFLAGS    := -std=gnu11 -O2 -g -Wall -Wextra -fPIC -I$(ROCM)/include -I$(CSRC) -Iinclude
 
-all: offt_amd/liboffthip.so oracle/liboracle.so tests/liboffthip_test.so
+all: offt_amd/liboffthip.so oracle/liboracle.so tests/liboffthip_test.so tools/liboffthip_diag.so
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -44,11 +44,18 @@ $(BUILD)/offt_host_test.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_
 tests/liboffthip_test.so: $(HIPOBJ) $(BUILD)/offt_host_test.o
 	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -Wl,-Bsymbolic -ldl -lm -lpthread
 
+# DIAGNOSTICS build for launchers (bench.py's exchange-only / compute-only split of a multi-rank run): the product plus
+# offt_hip_set_debug_skip, which makes an execute leave out its passes or its exchanges.  Never the measured library.
+$(BUILD)/offt_host_diag.o: $(CSRC)/offt_host.c $(CSRC)/offt_hipk.h $(CSRC)/offt_backend.h include/offt.h include/offt_hip.h | $(BUILD)
+	$(CC) $(CFLAGS) -DOFFT_BENCH_DIAGNOSTICS -c $< -o $@
+tools/liboffthip_diag.so: $(HIPOBJ) $(BUILD)/offt_host_diag.o
+	g++ -shared -o $@ $^ -Wl,--allow-shlib-undefined -Wl,-Bsymbolic -ldl -lm -lpthread
+
 oracle/liboracle.so: oracle/oracle_fft.c oracle/oracle_offt.c oracle/oracle.h
 	$(CC) -std=gnu11 -O3 -fopenmp -fPIC -shared -Ioracle -o $@ oracle/oracle_fft.c oracle/oracle_offt.c -lm
 
 clean:
-	rm -rf $(BUILD) offt_amd/liboffthip.so tests/liboffthip_test.so oracle/liboracle.so bin
+	rm -rf $(BUILD) offt_amd/liboffthip.so tests/liboffthip_test.so tools/liboffthip_diag.so oracle/liboracle.so bin
 
 .PHONY: all clean
 

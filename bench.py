@@ -284,23 +284,28 @@ def rank_main(args):
     tdt = torch.float64 if prec == api.F64 else torch.float32
     dist = None
     force_dist = bool(int(os.environ.get("OFFT_BENCH_FORCE_DIST", "0")))  # rehearse the multi-rank plumbing on one GPU
+
+    def join_world(lib):
+        """hand `lib` its world: rank 0 makes an RCCL id, torch.distributed ships the 128 bytes round"""
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            if lib.offt_hip_get_unique_id(buf):
+                raise SystemExit("offt_hip_get_unique_id failed: " + lib.offt_hip_last_error().decode())
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.cuda()
+        dist.broadcast(uid, src=0)
+        idb = bytes(uid.cpu().numpy().tobytes())
+        if lib.offt_hip_set_world(rank, world, idb, local_rank):
+            raise SystemExit("offt_hip_set_world failed: " + lib.offt_hip_last_error().decode())
+
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_char * 128)()
-            if L.offt_hip_get_unique_id(buf):
-                raise SystemExit("offt_hip_get_unique_id failed: " + L.offt_hip_last_error().decode())
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        uid = uid.cuda()
-        dist.broadcast(uid, src=0)
-        idb = bytes(uid.cpu().numpy().tobytes())
-        if L.offt_hip_set_world(rank, world, idb, local_rank):
-            raise SystemExit("offt_hip_set_world failed: " + L.offt_hip_last_error().decode())
+        join_world(L)
     multi = dist is not None
 
     n = args.n
@@ -320,6 +325,7 @@ def rank_main(args):
         return float(t.item())
 
     def make_plan(p1):
+        L = api.lib()
         params = {}
         if multi:
             params["P1"] = p1
@@ -339,7 +345,9 @@ def rank_main(args):
         once, as a caller that transforms a series of fields would do -- no host round trip between steps; the
         per-phase events exist only in the synchronous mode, so they come from a few extra steps afterwards."""
         ptr = data.data_ptr()
-        L.offt_hip_set_debug_skip(po, skip)
+        L = api.lib()  # (the diagnostics build once the extras have switched to it)
+        if skip:
+            L.offt_hip_set_debug_skip(po, skip)
         for _ in range(warmup):
             api.offt_3d_execute(po, ptr, ptr)
         pass_acc, dev_acc = [0.0, 0.0, 0.0], 0.0
@@ -375,7 +383,8 @@ def rank_main(args):
                 dev_acc += L.offt_hip_last_device_seconds(po)
             barrier()
             dt = max_over_ranks(time.perf_counter() - t0)
-        L.offt_hip_set_debug_skip(po, 0)
+        if skip:
+            L.offt_hip_set_debug_skip(po, 0)
         return dt, [x / steps for x in pass_acc], dev_acc / steps
 
     # ---- headline: K timed steps ----
@@ -419,10 +428,25 @@ def rank_main(args):
             out["ms_per_step_pipelined_error"] = repr(e)
 
     # ---- N > 1: what bounds the run?  (everything below is outside the headline's timed region) ----
-    if multi and not args.no_extras:
-        extra = {}
+    # The split timings need an execute that leaves out its passes or its exchanges: that switch exists only in the
+    # DIAGNOSTICS build (tools/liboffthip_diag.so, `make`), never in the product library the headline was measured with.
+    # The product's world is closed, the diagnostics build gets a world of its own, and the headline plan is made again there.
+    diag_path = os.path.join(ROOT, "tools", "liboffthip_diag.so")
+    if multi and not args.no_extras and not os.path.exists(diag_path):
+        out["multi_gpu"] = {"n_ranks_seen": int(L.offt_hip_world_count()), "note": "tools/liboffthip_diag.so not built: no split timings"}
+    elif multi and not args.no_extras:
+        extra = {"library": "tools/liboffthip_diag.so (product + offt_hip_set_debug_skip); the headline above used offt_amd/liboffthip.so"}
         try:
             extra["n_ranks_seen"] = int(L.offt_hip_world_count())
+            api.offt_3d_fin(po)
+            po = None
+            del data
+            torch.cuda.empty_cache()
+            barrier()
+            L.offt_hip_finalize_world()
+            L = api.use_library(diag_path)
+            join_world(L)
+            po, data = make_plan(p1_head)
             ksteps = max(2, min(5, steps))
             t_c, ps_c, _ = timed(po, data, ksteps, 1, skip=2)   # no exchanges
             t_x, _, _ = timed(po, data, ksteps, 1, skip=1)      # no FFT passes
@@ -435,9 +459,10 @@ def rank_main(args):
                 "xgmi": xgmi_block(g, esz, E, world, t_x / ksteps)}  # None for a group of one (one-GPU rehearsal)
         except Exception as e:  # extras never cost the headline
             extra["headline_split_error"] = repr(e)
-        api.offt_3d_fin(po)
-        po = None
-        del data
+        if po is not None:
+            api.offt_3d_fin(po)
+            po = None
+            del data
         torch.cuda.empty_cache()
         try:
             # the reference's default mesh: the largest divisor of p that is <= sqrt(p) (2 x 4 at 8 ranks)
@@ -492,7 +517,7 @@ def rank_main(args):
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        L.offt_hip_finalize_world()
+        api.lib().offt_hip_finalize_world()
         dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
 

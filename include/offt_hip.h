@@ -65,9 +65,25 @@ void offt_hip_set_async(struct _offt_plan *po, int async);
  * is bounded (OFFT_EXEC_TIMEOUT) and polls the RCCL communicators for asynchronous errors; returns 0, or -1 with
  * t[ALL] = 99999999 and the text in offt_hip_last_error().                                                        */
 int offt_hip_wait(struct _offt_plan *po);
-/* diagnostics for launchers: leave out the FFT passes (mask 1: exchange-only time) or the exchanges (mask 2:
- * compute-only time) of the multi-rank schedules.  Results are meaningless while a mask is set; 0 restores.       */
-void offt_hip_set_debug_skip(struct _offt_plan *po, int mask);
+/* plan-level options.  Each has an environment variable of the same meaning that is read ONCE, by offt_3d_init, as the
+ * default; after that a plan's behaviour does not depend on the process environment.  Options marked (collective) rebuild
+ * the plan's exchange buffers: every rank of the world calls them with the same value.  0 on success. */
+#define OFFT_HIP_OPT_ZGROUP_MIB 0      /* single rank: MiB per group of the alternating y / x launches; 0 off, -1 library rule (OFFT_ZGROUP_MIB) */
+#define OFFT_HIP_OPT_ZGROUP_STREAMS 1  /* ... 2 = consumer launches on a second stream (OFFT_ZGROUP_STREAMS) */
+#define OFFT_HIP_OPT_SLAB_CHUNK_MIB 2  /* (collective) slab schedule: largest z-chunk in MiB (OFFT_SLAB_CHUNK_MIB) */
+#define OFFT_HIP_OPT_COMM_STREAMS 3    /* pencil schedule: 2 = row and column exchanges on two streams (OFFT_COMM_STREAMS) */
+#define OFFT_HIP_OPT_F32_PAIRS 4       /* single precision: 0 = never the column-pair kernels (OFFT_F32_PAIRS) */
+#define OFFT_HIP_OPT_K1_STREAMS 5      /* slab schedule: 2 = FFTz launches of consecutive x-tiles on two streams (OFFT_K1_STREAMS) */
+#define OFFT_HIP_OPT_SELF_BYPASS 6     /* (collective) 0 = a rank's own block goes through the exchange like any other (OFFT_SELF_BYPASS) */
+#define OFFT_HIP_OPT_MIN_MSG 7         /* (collective) bytes a per-peer message is merged up to (OFFT_MIN_MSG) */
+#define OFFT_HIP_OPT_EXEC_TIMEOUT_S 8  /* bound of the final wait of a multi-rank execute (OFFT_EXEC_TIMEOUT) */
+#define OFFT_HIP_OPT_P2P_TIMEOUT_S 9   /* bound of one flag wait of the direct-store exchange (OFFT_P2P_TIMEOUT) */
+int offt_hip_set_option(struct _offt_plan *po, int option, long long value);
+/* (Launchers that want an exchange-only / compute-only split of a multi-rank execute link the DIAGNOSTICS build,
+ *  tools/liboffthip_diag.so = the product compiled with -DOFFT_BENCH_DIAGNOSTICS, which adds
+ *  void offt_hip_set_debug_skip(po, mask): mask 1 leaves out the FFT passes, 2 the exchanges.  The product library does
+ *  not contain it.) */
+long long offt_hip_get_option(const struct _offt_plan *po, int option);
 /* exchange of a multi-rank plan.  STAGED (default): the packing passes fill a send volume, grouped RCCL send/recv moves
  * it (the reference's pack + MPI_Ialltoall, offt-compute.c:1084-1109, 835-881); a rank's own block bypasses the exchange.
  * DIRECT: the packing passes store every block straight into its owner's receive volume (peer memory mapped through

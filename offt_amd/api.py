@@ -130,8 +130,14 @@ def bind(L):
     L.offt_hip_link_probe.argtypes = [i, i, C.c_longlong, i]
     L.offt_hip_wait.restype = i
     L.offt_hip_wait.argtypes = [PP]
-    L.offt_hip_set_debug_skip.restype = None
-    L.offt_hip_set_debug_skip.argtypes = [PP, i]
+    if hasattr(L, "offt_hip_set_debug_skip"):  # diagnostics / test builds only, never the product library
+        L.offt_hip_set_debug_skip.restype = None
+        L.offt_hip_set_debug_skip.argtypes = [PP, i]
+    L.offt_hip_set_exchange.argtypes = [PP, i]
+    L.offt_hip_get_exchange.argtypes = [PP]
+    L.offt_hip_set_option.argtypes = [PP, i, C.c_longlong]
+    L.offt_hip_get_option.restype = C.c_longlong
+    L.offt_hip_get_option.argtypes = [PP, i]
     L._offt_bound = True
     return L
 

@@ -58,6 +58,8 @@ typedef struct offt_pass_desc {
    * y pass has just written): store with the default cache policy so that it stays in L2 / the memory-side Infinity
    * Cache, instead of the streaming (non-temporal) stores every other pass uses */
   int out_keep;
+  /* single precision: 1 = do not use the column-pair kernels for this pass (plan option OFFT_HIP_OPT_F32_PAIRS) */
+  int no_pairs;
 } offt_pass_desc;
 
 /* Build device twiddle tables etc. for length n; call at plan time (allocates). */

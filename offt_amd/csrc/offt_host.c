@@ -386,11 +386,13 @@ typedef struct hip_state {
   int sT, sTz, sNt, sH;  /* slab schedule: x-tile, z-chunk thickness, #tiles, #chunks */
   int slab_yc;           /* slab blocks laid out [chunk][x_t][z in chunk][y] (y contiguous), see execute_slab() */
   size_t sblkS;          /* elements per (tile, peer) block of S1 / R1: [z_l][y][x_t] */
+  size_t sBc;            /* y-contiguous layout: pitch of a (peer, chunk) block = all its tiles + a de-aliasing pad (slab_setup) */
   void *S1, *R1, *R2;    /* packed send volume, receive volume (same layout), y-transformed volume */
   void **ev_s1;          /* per x-tile: K1 done */
   void **ev_sa;          /* per z-chunk: every tile's share of the chunk has arrived */
   int x1, x2;            /* exchange 1 / 2 really happen (p2 > 1 / p1 > 1, or forced for self-tests) */
-  size_t blk1, blk2;     /* elements per peer block: ex1 tile block, ex2 full block */
+  size_t blk1, blk2;     /* pitch of a peer block in elements: ex1 tile block, ex2 full block (both with a de-aliasing pad) */
+  size_t B2t;            /* pencil_yc: pitch of a (peer, x-tile) block of the exchange-2 volume = its H chunks + pad */
   int Tz2, H2;           /* pencil schedule, phase 2: z-chunk thickness (T2) and number of chunks of exchange 2 / FFTx */
   int pencil_yc;         /* pencil exchange volumes laid out y- / x-contiguous (two strided sides instead of four), see execute_pipeline() */
   void **ev_a2;          /* per z-chunk: the chunk's share of every x-tile has arrived (exchange 2) */
@@ -421,6 +423,18 @@ typedef struct hip_state {
   double out_scale;
   int yx_fused;        /* the last single-rank execute alternated launches i and i+1 over groups of planes: i + 1 (0: none) */
   void *s_aux, *ev_aux[4]; /* ... with the x launches on this second stream, ordered behind their y launch by these events */
+  /* plan-level options (offt_hip_set_option).  The environment variables of the same meaning are read ONCE, in
+   * offt_3d_init, as defaults: nothing below depends on the process environment after the plan exists */
+  struct {
+    int zgroup_mib;      /* single rank: group size of the alternating launches in MiB; 0 = off; -1 = the library's rule */
+    int zgroup_streams;  /* ... 2 = consumer launches on a second stream */
+    int slab_chunk_mib;  /* slab schedule: largest z-chunk of the y-transformed volume (Infinity-Cache reuse K2 -> K3) */
+    int comm_streams;    /* pencil schedule: 2 = row and column exchanges on separate streams */
+    long long min_msg;   /* tiles are merged upwards until a per-peer message has this many bytes */
+    int f32_pairs;       /* single precision: 0 = never use the column-pair kernels */
+    int block_pad;       /* exchange volumes: per-peer / per-chunk blocks padded against HBM channel aliasing */
+    double exec_timeout_s, p2p_timeout_s;
+  } opt;
   double *agree_d, *agree_h; /* world_max(): 2 p doubles on the device and on the host, made once at plan time so that the
                                 agreement itself never allocates (it runs right after a rank may have run out of memory) */
   int k1_streams;      /* slab schedule: 2 = the K1 launches of consecutive x-tiles alternate between two streams, so that one tile's
@@ -643,6 +657,7 @@ static void desc_init(offt_pass_desc *d, const hip_state *st, int n, int dir, in
   d->nb1 = d->nb2 = 1;
   d->variant = st->variant[axis];
   d->scale = 1.0;
+  d->no_pairs = !st->opt.f32_pairs;
 }
 
 /* device copy of a per-block base table (offt_pass_desc::in_block_tab / out_block_tab): block b of the split axis sits
@@ -709,7 +724,7 @@ static int p2p_wait(hip_state *st, const p2p_group *g, int slot, unsigned long l
   unsigned long long *addr[OFFT_HIPK_MAX_FLAGS];
   if (value == 0) return 0;
   for (int a = 0; a < g->n; a++) addr[a] = g->flags + (size_t)slot * g->n + a;
-  const double limit = getenv("OFFT_P2P_TIMEOUT") ? atof(getenv("OFFT_P2P_TIMEOUT")) : 30.0;
+  const double limit = st->opt.p2p_timeout_s;
   P2P_HOOK(); /* (thread worlds of the tests: every signal this wait depends on is enqueued by now) */
   return st->be->flag_wait(g->n, addr, value, st->p2p_status, limit, stream);
 }
@@ -782,7 +797,7 @@ static void ring_teardown(hip_state *st) {
 static int ring_setup(struct _offt_plan *po, hip_state *st) {
   const offt_backend *be = st->be;
   const struct _offt_comm *c = po->comm;
-  const size_t min_msg = (size_t)(getenv("OFFT_MIN_MSG") ? atol(getenv("OFFT_MIN_MSG")) : 4L << 20);
+  const size_t min_msg = (size_t)st->opt.min_msg;
   /* phase 1: x-tiles of T1 planes, W1 + 1 ring slots.  Unless the caller fixed T1 the tile is merged upwards until a
    * per-peer message of exchange 1 is at least 4 MiB (the reference's M1/16 was sized for CPU caches and MPI eager limits) */
   st->T = po->params->v[_T1_];
@@ -790,7 +805,9 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (!st->t1_custom) {
     /* at most 8 tiles: the reference's M1/16 gives 54-us launches at 1024^3 on 8 ranks (two rounds of workgroups per
      * launch, 61 % instead of 75 % of the roofline; profiles/r02_rehearse_f64_1024_2x4_first.txt) */
-    const int t8 = (c->M1 + 7) / 8;
+    /* (... and at most 4 since round 3, like the slab schedule: 2.46 -> 2.28 ms of kernels per rank at 1024^3 on a 2 x 4 mesh,
+     * profiles/r03_rehearse_touch.txt) */
+    const int t8 = (c->M1 + 3) / 4;
     if (st->T < t8) st->T = t8;
     while (st->T < c->M1 && (size_t)st->T * c->M2 * c->M3 * st->esz < min_msg) st->T *= 2;
   }
@@ -800,7 +817,9 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (W < 0) W = 0;
   st->ring = W + 1;
   if (st->ring > st->ntiles) st->ring = st->ntiles;
-  st->blk1 = (size_t)st->T * c->M2 * c->M3;
+  /* (block pitches carry a pad of nine 128-B lines: peer blocks a power of two apart alias onto the same HBM channels, see slab_setup) */
+  const size_t padE = st->opt.block_pad ? 1152 / st->esz : 0;
+  st->blk1 = (size_t)st->T * c->M2 * c->M3 + padE;
   st->send1 = (void **)calloc(st->ring, sizeof(void *));
   st->recv1 = (st->x1 && !st->p2p) ? (void **)calloc(st->ring, sizeof(void *)) : st->send1;
   st->ev_k1 = (void **)calloc(st->ring, sizeof(void *));
@@ -833,10 +852,11 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (Tz > c->M3) Tz = c->M3;
   st->Tz2 = Tz;
   st->H2 = (c->M3 + Tz - 1) / Tz;
-  st->blk2 = (size_t)c->M1 * c->M4 * c->M3;
   /* contiguous-line layouts of both exchange volumes need even x and z blocks made of whole tiles / chunks */
   st->pencil_yc = c->b1 == 0 && c->b3 == 0 && c->M1 % st->T == 0 && c->M3 % Tz == 0 &&
                   !(getenv("OFFT_PENCIL_ZC_LAYOUT") && atoi(getenv("OFFT_PENCIL_ZC_LAYOUT")));
+  st->B2t = (size_t)st->H2 * Tz * c->M4 * st->T + padE;
+  st->blk2 = st->pencil_yc ? (size_t)st->ntiles * st->B2t : (size_t)c->M1 * c->M4 * c->M3 + padE;
   st->recv2 = be->dmalloc(st->blk2 * c->p1 * st->esz);
   st->send2 = (st->x2 && !st->p2p) ? be->dmalloc(st->blk2 * c->p1 * st->esz) : st->recv2;
   if (!st->recv2 || !st->send2) return -1;
@@ -856,7 +876,7 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (st->self_bypass && st->x2 && c->p1 > 1 && !st->p2p) {
     int ok = 1;
     const long long delta = elem_delta(st, st->recv2, st->send2, &ok);
-    const long long stride = st->pencil_yc ? (long long)st->ntiles * st->H2 * ((long long)Tz * c->M4 * st->T) : (long long)st->blk2;
+    const long long stride = (long long)st->blk2;
     if (ok) st->tab_x2 = tab_self(st, c->p1, 1, stride, po->rank / c->p2, delta);
   }
   return 0;
@@ -957,9 +977,9 @@ static int p2p_open(struct _offt_plan *po, hip_state *st) {
     st->peer_r1 = (void **)calloc((size_t)p2, sizeof(void *));
     if (!st->use1 || !st->peer_r1) return -1;
     if (st->slab_zyx) {
-      const size_t bytes = st->sblkS * p2 * st->sNt * st->esz;
+      const size_t bytes = (st->slab_yc ? st->sBc * st->sH : st->sblkS * st->sNt) * p2 * st->esz;
       if (be->peer_open(st, 1, p2, ry, st->R1, bytes, st->peer_r1)) return -1;
-      st->tab_p1 = st->slab_yc ? tab_peers(st, p2, st->sH, (long long)c->M2 * st->sTz * st->sT * st->sNt, ry, st->peer_r1, st->R1)
+      st->tab_p1 = st->slab_yc ? tab_peers(st, p2, st->sH, (long long)st->sBc, ry, st->peer_r1, st->R1)
                                : tab_peers(st, p2, 1, (long long)st->sblkS, ry, st->peer_r1, st->R1);
       if (!st->tab_p1) return -1;
     } else {
@@ -981,7 +1001,7 @@ static int p2p_open(struct _offt_plan *po, hip_state *st) {
     st->peer_x2 = (void **)calloc((size_t)p1, sizeof(void *));
     if (!st->peer_x2) return -1;
     if (be->peer_open(st, 2, p1, rx, st->recv2, st->blk2 * p1 * st->esz, st->peer_x2)) return -1;
-    const long long stride = st->pencil_yc ? (long long)st->ntiles * st->H2 * ((long long)st->Tz2 * c->M4 * st->T) : (long long)st->blk2;
+    const long long stride = (long long)st->blk2;
     st->tab_p2 = tab_peers(st, p1, 1, stride, rx, st->peer_x2, st->recv2);
     if (!st->tab_p2) return -1;
   }
@@ -1047,6 +1067,15 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->out_scale = 1.0;
   st->self_bypass = !(getenv("OFFT_SELF_BYPASS") && atoi(getenv("OFFT_SELF_BYPASS")) == 0);
   st->k1_streams = getenv("OFFT_K1_STREAMS") ? atoi(getenv("OFFT_K1_STREAMS")) : 1;
+  st->opt.zgroup_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : -1;
+  st->opt.zgroup_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) : 1;
+  st->opt.slab_chunk_mib = getenv("OFFT_SLAB_CHUNK_MIB") ? atoi(getenv("OFFT_SLAB_CHUNK_MIB")) : 256;
+  st->opt.comm_streams = getenv("OFFT_COMM_STREAMS") ? atoi(getenv("OFFT_COMM_STREAMS")) : 1;
+  st->opt.min_msg = getenv("OFFT_MIN_MSG") ? atoll(getenv("OFFT_MIN_MSG")) : 4LL << 20;
+  st->opt.f32_pairs = !(getenv("OFFT_F32_PAIRS") && atoi(getenv("OFFT_F32_PAIRS")) == 0);
+  st->opt.block_pad = !(getenv("OFFT_BLOCK_PAD") && atoi(getenv("OFFT_BLOCK_PAD")) == 0);
+  st->opt.exec_timeout_s = getenv("OFFT_EXEC_TIMEOUT") ? atof(getenv("OFFT_EXEC_TIMEOUT")) : 120.0;
+  st->opt.p2p_timeout_s = getenv("OFFT_P2P_TIMEOUT") ? atof(getenv("OFFT_P2P_TIMEOUT")) : 30.0;
   st->want_p2p = getenv("OFFT_EXCHANGE") && !strcmp(getenv("OFFT_EXCHANGE"), "p2p");
   /* scratch planes are offset by an odd number of 128-B lines (9 = 1152 B) so that the x-planes a
    * y-pass panel reads do not alias onto the same HBM channels (sweep: profiles/r01_sweep.txt).  In
@@ -1107,7 +1136,7 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
      * default both exchanges are issued on ONE comm stream, in the same order on every rank (no cross-communicator wait
      * cycle is possible); OFFT_COMM_STREAMS=2 gives each exchange its own stream (they then overlap on the wire). */
     st->s_comm1 = be->stream_create();
-    st->s_comm2 = (getenv("OFFT_COMM_STREAMS") && atoi(getenv("OFFT_COMM_STREAMS")) >= 2) ? be->stream_create() : st->s_comm1;
+    st->s_comm2 = st->opt.comm_streams >= 2 ? be->stream_create() : st->s_comm1;
     if (!st->s_comm1 || !st->s_comm2) goto fail;
     if (po->p > 1) {
       st->agree_d = (double *)be->dmalloc(sizeof(double) * 2 * (size_t)po->p);
@@ -1476,10 +1505,64 @@ int offt_hip_set_exchange(struct _offt_plan *po, int mode) {
   if (world_max(po, &bad) || bad > 0.0) { SET_ERR("offt_hip_set_exchange: a rank could not rebuild its buffers"); return -1; }
   return st->p2p ? OFFT_HIP_EXCHANGE_DIRECT : OFFT_HIP_EXCHANGE_STAGED;
 }
+/* plan-level options (offt_hip.h).  Options that shape buffers (slab chunk, comm streams, minimum message, self bypass)
+ * rebuild the mesh like offt_hip_set_exchange and are therefore collective. */
+int offt_hip_set_option(struct _offt_plan *po, int option, long long value) {
+  hip_state *st = (hip_state *)po->hip_state;
+  int rebuild = 0;
+  switch (option) {
+    case OFFT_HIP_OPT_ZGROUP_MIB: st->opt.zgroup_mib = (int)value; break;
+    case OFFT_HIP_OPT_ZGROUP_STREAMS: st->opt.zgroup_streams = (int)value; break;
+    case OFFT_HIP_OPT_F32_PAIRS: st->opt.f32_pairs = value != 0; break;
+    case OFFT_HIP_OPT_K1_STREAMS: st->k1_streams = (int)value; break;
+    case OFFT_HIP_OPT_EXEC_TIMEOUT_S: st->opt.exec_timeout_s = (double)value; break;
+    case OFFT_HIP_OPT_P2P_TIMEOUT_S: st->opt.p2p_timeout_s = (double)value; break;
+    case OFFT_HIP_OPT_SLAB_CHUNK_MIB: st->opt.slab_chunk_mib = (int)value; rebuild = 1; break;
+    case OFFT_HIP_OPT_MIN_MSG: st->opt.min_msg = value; rebuild = 1; break;
+    case OFFT_HIP_OPT_SELF_BYPASS: st->self_bypass = value != 0; rebuild = 1; break;
+    case OFFT_HIP_OPT_COMM_STREAMS:
+      if (st->use_pipeline && (value >= 2) != (st->opt.comm_streams >= 2)) {
+        if (st->be->stream_sync(st->s_compute)) return -1;
+        if (st->s_comm2 != st->s_comm1) st->be->stream_destroy(st->s_comm2);
+        st->s_comm2 = value >= 2 ? st->be->stream_create() : st->s_comm1;
+        if (!st->s_comm2) { st->s_comm2 = st->s_comm1; return -1; }
+      }
+      st->opt.comm_streams = (int)value;
+      break;
+    default: SET_ERR("offt_hip_set_option: unknown option %d", option); return -1;
+  }
+  if (rebuild && st->use_pipeline) {
+    if (st->be->stream_sync(st->s_compute)) return -1;
+    mesh_teardown(st);
+    double bad = mesh_setup(po, st) ? 1.0 : 0.0;
+    if (world_max(po, &bad) || bad > 0.0) { SET_ERR("offt_hip_set_option: a rank could not rebuild its buffers"); return -1; }
+  }
+  return 0;
+}
+long long offt_hip_get_option(const struct _offt_plan *po, int option) {
+  const hip_state *st = (const hip_state *)po->hip_state;
+  switch (option) {
+    case OFFT_HIP_OPT_ZGROUP_MIB: return st->opt.zgroup_mib;
+    case OFFT_HIP_OPT_ZGROUP_STREAMS: return st->opt.zgroup_streams;
+    case OFFT_HIP_OPT_F32_PAIRS: return st->opt.f32_pairs;
+    case OFFT_HIP_OPT_K1_STREAMS: return st->k1_streams;
+    case OFFT_HIP_OPT_EXEC_TIMEOUT_S: return (long long)st->opt.exec_timeout_s;
+    case OFFT_HIP_OPT_P2P_TIMEOUT_S: return (long long)st->opt.p2p_timeout_s;
+    case OFFT_HIP_OPT_SLAB_CHUNK_MIB: return st->opt.slab_chunk_mib;
+    case OFFT_HIP_OPT_MIN_MSG: return st->opt.min_msg;
+    case OFFT_HIP_OPT_SELF_BYPASS: return st->self_bypass;
+    case OFFT_HIP_OPT_COMM_STREAMS: return st->opt.comm_streams;
+    default: return -1;
+  }
+}
 int offt_hip_get_exchange(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->p2p ? OFFT_HIP_EXCHANGE_DIRECT : OFFT_HIP_EXCHANGE_STAGED; }
 void offt_hip_set_output_scale(struct _offt_plan *po, double scale) { ((hip_state *)po->hip_state)->out_scale = scale; }
 void offt_hip_set_async(struct _offt_plan *po, int async) { ((hip_state *)po->hip_state)->async = async; }
+#if defined(OFFT_TEST_SEAMS) || defined(OFFT_BENCH_DIAGNOSTICS)
+/* diagnostics (compiled into the test build and into builds made with -DOFFT_BENCH_DIAGNOSTICS only): leave out the FFT
+ * passes (mask 1) or the exchanges (mask 2) of the multi-rank schedules -- results are meaningless while a mask is set */
 void offt_hip_set_debug_skip(struct _offt_plan *po, int mask) { ((hip_state *)po->hip_state)->skip_mask = mask; }
+#endif
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
 }
@@ -1635,11 +1718,11 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   if (zyx) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
   else if (S || dir < 0) { ia = 0; cnt = Nx; plane_elems = (double)Ny * Nz; len_a = Nzf; len_b = Ny; }
   if (ia >= 0 && d[ia].nb1 == cnt && d[ia + 1].nb1 == cnt && !d[ia].real_input &&
-      (getenv("OFFT_ZGROUP_MIB") || (len_a <= 1024 && len_b <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
+      (st->opt.zgroup_mib >= 0 || (len_a <= 1024 && len_b <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
     const int ib = ia + 1;
-    const int group_mib = getenv("OFFT_ZGROUP_MIB") ? atoi(getenv("OFFT_ZGROUP_MIB")) : 256;
+    const int group_mib = st->opt.zgroup_mib >= 0 ? st->opt.zgroup_mib : 256;
     /* OFFT_ZGROUP_STREAMS=2: consumer launches on a second stream (then 128 MiB groups do as well as 256 MiB on one stream) */
-    const int two_streams = getenv("OFFT_ZGROUP_STREAMS") ? atoi(getenv("OFFT_ZGROUP_STREAMS")) >= 2 : 0;
+    const int two_streams = st->opt.zgroup_streams >= 2;
     const double plane_mib = plane_elems * (double)st->esz / (1024.0 * 1024.0);
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
@@ -1857,7 +1940,7 @@ static void slab_teardown(hip_state *st) {
 static int slab_setup(struct _offt_plan *po, hip_state *st) {
   const offt_backend *be = st->be;
   const struct _offt_comm *c = po->comm;
-  const size_t min_msg = (size_t)(getenv("OFFT_MIN_MSG") ? atol(getenv("OFFT_MIN_MSG")) : 4L << 20);
+  const size_t min_msg = (size_t)st->opt.min_msg;
   int T = po->params->v[_T1_], Tz = po->params->v[_T2_];
   if (T < 1) T = 1;
   if (Tz < 1) Tz = 1;
@@ -1868,7 +1951,7 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
     /* ... but no chunk of R2 larger than the Infinity Cache: K2(h) leaves its chunk there for K3(h) (out_keep).  Per-rank
      * kernels of 2048^3 f32 on 8 ranks: 9.54 ms with 1 GiB chunks, 9.03 ms with 256 MiB ones; 1024^3 f64 has 256 MiB
      * chunks either way (profiles/r02_rehearse_chunks.txt).  More chunks also means a finer exchange pipeline. */
-    const int chunk_mib = getenv("OFFT_SLAB_CHUNK_MIB") ? atoi(getenv("OFFT_SLAB_CHUNK_MIB")) : 256;
+    const int chunk_mib = st->opt.slab_chunk_mib;
     const double plane_mib = (double)c->M4 * (double)c->M1 * (double)st->esz / (1024.0 * 1024.0);
     const int tzc = chunk_mib > 0 ? (int)((double)chunk_mib / plane_mib) : 0;
     if (tzc >= 1 && Tz > tzc) { Tz = tzc; while (Tz > 1 && c->M3 % Tz) Tz--; }
@@ -1881,12 +1964,17 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->sblkS = (size_t)c->M3 * c->M2 * T;
   /* y-contiguous block layout (see execute_slab): needs even z blocks that are whole chunks */
   st->slab_yc = c->b3 == 0 && c->M3 % Tz == 0 && !(getenv("OFFT_SLAB_XC_LAYOUT") && atoi(getenv("OFFT_SLAB_XC_LAYOUT")));
+  /* y-contiguous layout: a (peer, chunk) block holds its nt tiles, then a pad of nine 128-B lines.  Without it the p2 * H
+   * blocks one K1 workgroup stores into (and the p2 blocks a K2 line is read from) sit a power of two apart -- 32 MiB at
+   * 1024^3 on 8 ranks -- and fall on the same HBM channels, like the x-planes of the single-rank scratch volume (wpad) */
+  st->sBc = (size_t)c->M2 * Tz * T * st->sNt + (st->opt.block_pad ? 1152 / st->esz : 0);
+  const size_t vol = (st->slab_yc ? st->sBc * st->sH : st->sblkS * st->sNt) * c->p2;
   /* (direct-store exchange: no send volume -- K1 stores into the peers' R1, its own block into its own) */
-  if (!(st->p2p && st->x1)) st->S1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
+  if (!(st->p2p && st->x1)) st->S1 = be->dmalloc(vol * st->esz);
   st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
   if ((!st->S1 && !(st->p2p && st->x1)) || !st->R2) return -1;
   if (st->x1) {
-    st->R1 = be->dmalloc(st->sblkS * c->p2 * st->sNt * st->esz);
+    st->R1 = be->dmalloc(vol * st->esz);
     if (!st->R1) return -1;
   }
   st->ev_s1 = (void **)calloc(st->sNt, sizeof(void *));
@@ -1898,7 +1986,7 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   if (st->self_bypass && st->x1 && c->p2 > 1 && !st->p2p) {
     int ok = 1;
     const long long delta = elem_delta(st, st->R1, st->S1, &ok);
-    if (ok) st->tab_s1 = st->slab_yc ? tab_self(st, c->p2, st->sH, (long long)c->M2 * Tz * T * st->sNt, po->rank % c->p2, delta)
+    if (ok) st->tab_s1 = st->slab_yc ? tab_self(st, c->p2, st->sH, (long long)st->sBc, po->rank % c->p2, delta)
                                      : tab_self(st, c->p2, 1, (long long)st->sblkS, po->rank % c->p2, delta);
   }
   return 0;
@@ -1944,7 +2032,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.ncols = c->m2; d.nb1 = myT;
         d.in_col_stride = c->istride[1]; d.in_b1_stride = c->istride[0];
         d.out_axis_stride = c->M2; d.out_col_stride = 1; d.out_b1_stride = (long long)Tz * c->M2;
-        d.out_split = Tz; d.out_block_stride = (long long)c->M2 * Tz * T * nt; /* [peer][chunk][tile]: a (peer, chunk) run holds all tiles */
+        d.out_split = Tz; d.out_block_stride = (long long)st->sBc; /* [peer][chunk][tile]: a (peer, chunk) run holds all tiles (+ pad) */
       } else {
         d.ncols = myT; d.nb1 = c->m2;
         d.in_col_stride = c->istride[0]; d.in_b1_stride = c->istride[1];
@@ -1985,7 +2073,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
             if (st->tab_s1 && a == po->rank % p2) continue; /* K1 stored this rank's own block straight into R1 */
             const int e = cnt++;
             const size_t B = (size_t)c->M2 * Tz * T;
-            const size_t off = st->slab_yc ? ((((size_t)a * H + h) * nt + (merged ? 0 : i)) * B) * esz
+            const size_t off = st->slab_yc ? (((size_t)a * H + h) * st->sBc + (merged ? 0 : (size_t)i) * B) * esz
                                            : (((size_t)i * p2 + a) * st->sblkS + (size_t)z0 * c->M2 * T) * esz;
             pr[e] = peers[a];
             sp[e] = (char *)st->S1 + off;
@@ -2006,8 +2094,8 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     if (st->x1 && !p2p) be->stream_wait(s, st->ev_sa[h]);
     /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
     if (nz > 0) {
-      const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (st->slab_yc ? (size_t)h * nt * c->M2 * Tz * T : (size_t)z0 * c->M2 * T) * esz;
-      const size_t blk = st->slab_yc ? st->sblkS * nt : st->sblkS;  /* peer block */
+      const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (st->slab_yc ? (size_t)h * st->sBc : (size_t)z0 * c->M2 * T) * esz;
+      const size_t blk = st->slab_yc ? st->sBc * H : st->sblkS;  /* peer block */
       for (int part = 0; part < 2; part++) { /* full tiles in one launch, the ragged tile in another */
         const int ntile = part == 0 ? nfull : (tail > 0 ? 1 : 0);
         if (!ntile) continue;
@@ -2175,10 +2263,10 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
         d.out_b2_stride = (long long)B2; /* volume [peer][x-tile][z-chunk]: all chunks of a (peer, tile) are one contiguous message */
         if (p1 > 1) { /* peer a owns y in [a*F4, ..): offt-compute.c:1758-1776 */
           d.out_split = c->F4; d.out_split_nfloor = c->b4 ? p1 - c->b4 : 0;
-          d.out_block_stride = (long long)st->ntiles * H * B2;
+          d.out_block_stride = (long long)st->blk2;
           d.out_block_tab = pp2 ? st->tab_p2 : st->tab_x2; /* (relative to the launch pointer: tile / chunk offsets are the same in send2 and every recv2) */
         }
-        if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * H * B2 * esz, s, 0)) return -1;
+        if (run_pass(st, &d, st->recv1[r], (char *)st->send2 + (size_t)k * st->B2t * esz, s, 0)) return -1;
       }
       for (int part = 0; part < 2 && myT > 0 && !st->pencil_yc; part++) {
         /* the chunks this rank fills completely go in one launch (chunk = second batch dimension), the ragged last
@@ -2229,7 +2317,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
               const int e = cnt++;
               int ma = blk_size(a, c->F1, c->b1, p1) - x0; if (ma > T) ma = T; if (ma < 0) ma = 0;
               const size_t off = st->pencil_yc
-                                     ? (((size_t)a * st->ntiles + k) * H + (merged ? 0 : h)) * (size_t)Tz * c->M4 * T * esz
+                                     ? ((size_t)a * st->blk2 + (size_t)k * st->B2t + (merged ? 0 : (size_t)h) * (size_t)Tz * c->M4 * T) * esz
                                      : ((size_t)a * st->blk2 + (size_t)z0 * MM + (size_t)x0 * c->M4 * tzh) * esz;
               const size_t nch = merged ? (size_t)H : (size_t)1;
               pr[e] = peers2[a];
@@ -2266,7 +2354,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const size_t B2 = (size_t)Tz * c->M4 * T;
       d.ncols = c->m4; d.nb1 = nz;
       d.in_axis_stride = 1; d.in_contig = 1; d.in_col_stride = T; d.in_b1_stride = (long long)c->M4 * T;
-      d.in_split = T; d.in_block_stride = (long long)H * B2; /* (peer, tile) blocks are H chunks apart */
+      d.in_split = T; d.in_block_stride = (long long)st->B2t; /* (peer, tile) blocks are H chunks (+ pad) apart, peers ntiles of them */
       d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2];
       if (run_pass(st, &d, (char *)st->recv2 + (size_t)h * B2 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
       continue;
@@ -2324,7 +2412,7 @@ static int comm_async_error(hip_state *st) {
  * a dead or stuck peer becomes the failure marker t[ALL] = 99999999 plus offt_hip_last_error(), not a hang. */
 static int wait_compute_ex(hip_state *st, int watch) {
   if (!watch) return st->be->stream_sync(st->s_compute);
-  const double limit = getenv("OFFT_EXEC_TIMEOUT") ? atof(getenv("OFFT_EXEC_TIMEOUT")) : 120.0;
+  const double limit = st->opt.exec_timeout_s;
   const double t0 = wall_seconds();
   double tchk = t0;
   for (;;) {

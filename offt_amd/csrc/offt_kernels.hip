@@ -770,7 +770,7 @@ Variant *pick_variant0(const offt_pass_desc *d, bool allow_pair) {
   const bool odd_split = (d->in_split && !is_pow2(d->in_split)) || (d->out_split && !is_pow2(d->out_split));
   static const bool pairs_on = !(getenv("OFFT_F32_PAIRS") && atoi(getenv("OFFT_F32_PAIRS")) == 0);
   int want = d->variant;
-  if (want >= VARIANT_PAIR0 || (want < 0 && pairs_on)) {
+  if (want >= VARIANT_PAIR0 || (want < 0 && pairs_on && !d->no_pairs)) {
     if (allow_pair && !uneven && !odd_split && pair_ok(d)) {
       Variant *p = find_variant(d->n, OFFT_PREC_F32_PAIR, inc, outc, want < 0 ? -1 : want - VARIANT_PAIR0);
       if (p && (want >= 0 ? p->id == want - VARIANT_PAIR0 : p->is_default)) return p;

@@ -65,7 +65,14 @@ def main():
         state["p1"] = p1
         L.offt_hip_test_set_transport(C.cast(cb, C.c_void_p), rank, size)
         r2c = case.get("r2c", 0)
+        if case.get("p2p"):
+            # direct-store exchange between PROCESSES: the product's own hipIpc path (handles gathered through the
+            # transport above, opened with hipIpcOpenMemHandle) -- the kernels of one process store into another's buffers
+            os.environ["OFFT_EXCHANGE"] = "p2p"
         po = api.offt_3d_init(*shape, custom_params=api.make_params(**case["params"]), is_equalxy=case.get("eq", 0), is_r2c=r2c)
+        os.environ.pop("OFFT_EXCHANGE", None)
+        L.offt_hip_get_exchange.argtypes = [C.c_void_p]
+        exchange = L.offt_hip_get_exchange(po)
         c = api.comm_dict(po)
         v = list(po.contents.params.contents.v)
         dev = torch.zeros(api.local_elems(po) * 2, dtype=torch.float64, device="cuda")
@@ -75,6 +82,12 @@ def main():
         api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
         buf = dev.cpu().numpy().view(np.complex128)
         np.save(os.path.join(outdir, f"case{ci}_rank{rank}.npy"), buf)
+        for _ in range(case.get("repeat", 0)):  # the same plan again: buffer reuse between transforms
+            if L.offt_hip_fill_input(po, dev.data_ptr(), 1):
+                raise SystemExit("fill failed")
+            api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+            if not np.array_equal(dev.cpu().numpy().view(np.complex128), buf):
+                raise SystemExit("repeat: result differs from the first transform")
         if case.get("inv"):
             torch.cuda.synchronize()
             api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
@@ -82,7 +95,7 @@ def main():
             np.save(os.path.join(outdir, f"case{ci}_rank{rank}_inv.npy"),
                     cpu_world.input_block(c, dev.cpu().numpy().view(np.complex128)))
         api.offt_3d_fin(po)
-        json.dump({"comm": c, "v": v}, open(os.path.join(outdir, f"case{ci}_rank{rank}.json"), "w"))
+        json.dump({"comm": c, "v": v, "exchange": exchange}, open(os.path.join(outdir, f"case{ci}_rank{rank}.json"), "w"))
         dist.barrier()
     L.offt_hip_test_set_transport(None, 0, 1)
     dist.destroy_process_group()

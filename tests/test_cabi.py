@@ -77,6 +77,10 @@ def test_product_library_has_no_test_seams(built):
     import subprocess
     syms = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
     assert "offt_hip_test_" not in syms
+    # ... nor the diagnostic switch that makes an execute skip its passes or its exchanges (tools/liboffthip_diag.so has it)
+    assert "offt_hip_set_debug_skip" not in syms
+    dsyms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tools", "liboffthip_diag.so")]).decode()
+    assert "offt_hip_set_debug_skip" in dsyms and "offt_hip_test_" not in dsyms
     tsyms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tests", "liboffthip_test.so")]).decode()
     assert "offt_hip_test_set_backend" in tsyms and "offt_hip_test_set_transport" in tsyms
 

@@ -47,6 +47,8 @@ def run_world(size, cases, tmp_path):
                 back = np.load(tmp_path / f"case{ci}_rank{r}_inv.npy")
                 blk = O.hash_field(*meta["isize"], *meta["istart"])
                 assert np.linalg.norm(back / np.prod(shape) - blk) / np.linalg.norm(blk) < 1e-13, (case, r)
+        if case.get("p2p"):  # the direct-store exchange was really in use (no silent fall-back to the staged one)
+            assert all(json.load(open(tmp_path / f"case{ci}_rank{r}.json"))["exchange"] == 1 for r in range(size)), case
 
 
 def run_thread_world(size, cases, tmp_path):
@@ -138,3 +140,42 @@ def test_three_ranks_one_gpu_uneven_blocks(built, tmp_path):
              dict(N=[128, 96, 64], params=dict(P1=1), r2c=1), dict(N=[20, 14, 18], params=dict(P1=1, S=1))]
     run_world(3, cases, tmp_path)
 
+
+
+def test_direct_store_exchange_thread_worlds(built, tmp_path):
+    """The direct-store exchange (OFFT_EXCHANGE=p2p) on the GPU, ranks as threads sharing the card: the packing kernels of
+    one rank store straight into the other ranks' receive volumes (a peer pointer here is another thread's device buffer),
+    flag kernels order the streams -- no transport, no host synchronisation inside a transform.  The bench meshes 1 x 8,
+    2 x 4, 8 x 1, ragged grids, single precision, the barrier-mirrored inverse, and plans used several times in a row
+    (buffer reuse: FREE flags); forward -> inverse -> forward on one plan."""
+    cases = [dict(N=[256, 256, 256], params=dict(P1=1), p2p=1, repeat=2), dict(N=[256, 256, 256], params=dict(), p2p=1, repeat=2),
+             dict(N=[256, 256, 256], params=dict(P1=8), p2p=1, repeat=1),
+             dict(N=[100, 72, 90], params=dict(P1=2, T1=7, T2=5), p2p=1, repeat=1), dict(N=[100, 72, 90], params=dict(P1=1), p2p=1, inv=1),
+             dict(N=[128, 128, 128], params=dict(), p2p=1, inv=1, repeat=1), dict(N=[128, 128, 128], params=dict(P1=1), p2p=1, inv=1, repeat=1),
+             dict(N=[128, 64, 256], params=dict(P1=4), r2c=1, p2p=1), dict(N=[128, 128, 128], params=dict(P1=4, S=1, T2=8), p2p=1),
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), p2p=1, env=dict(OFFT_PENCIL_ZC_LAYOUT=1)),
+             dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=4), p2p=1, env=dict(OFFT_SLAB_XC_LAYOUT=1)),
+             dict(N=[256, 256, 256], params=dict(P1=1), f32=1, p2p=1, repeat=1), dict(N=[256, 256, 256], params=dict(), f32=1, p2p=1, inv=1)]
+    s = run_thread_world(8, cases, tmp_path)
+    assert s[1]["mesh"] == [2, 4]
+    run_thread_world(3, [dict(N=[64, 64, 64], params=dict(P1=1), p2p=1, repeat=1), dict(N=[100, 96, 120], params=dict(P1=3), p2p=1, inv=1),
+                         dict(N=[128, 100, 96], params=dict(P1=3), f32=1, p2p=1)], tmp_path)
+
+
+def test_direct_store_exchange_full_size_eight_ranks_one_gpu(built, tmp_path):
+    """BASELINE configs[3] at full size with the direct-store exchange: 1024^3 over 8 thread-ranks, 1 x 8 and 2 x 4"""
+    n = 1024
+    spots = [[0, 0, 0], [0, 0, 1], [0, 0, 1023], [0, 5, 0], [7, 0, 0], [1, 1, 1], [1023, 1023, 1023], [0, 511, 640], [300, 0, 900]]
+    cases = [dict(N=[n, n, n], params=dict(P1=1), check="ramp", spots=spots, p2p=1), dict(N=[n, n, n], params=dict(), check="ramp", spots=spots, p2p=1)]
+    s = run_thread_world(8, cases, tmp_path)
+    assert s[0]["mesh"] == [1, 8] and s[1]["mesh"] == [2, 4]
+
+
+def test_direct_store_exchange_between_processes_hipipc(built, tmp_path):
+    """... and between PROCESSES sharing the card: the product's hipIpc path (hipIpcGetMemHandle, handles gathered with the
+    exchange primitive, hipIpcOpenMemHandle) -- what a one-process-per-GPU run uses, here with both ends on one device"""
+    cases = [dict(N=[64, 64, 64], params=dict(P1=1), p2p=1, repeat=2), dict(N=[64, 64, 64], params=dict(P1=2), p2p=1, repeat=1),
+             dict(N=[128, 64, 32], params=dict(P1=1, T1=16, T2=4), p2p=1, inv=1), dict(N=[18, 20, 14], params=dict(P1=1, T1=4, T2=3), p2p=1),
+             dict(N=[64, 32, 16], params=dict(P1=2, T1=8), p2p=1, inv=1, repeat=1)]
+    run_world(2, cases, tmp_path)
+    run_world(4, [dict(N=[64, 64, 64], params=dict(P1=2), p2p=1, repeat=1), dict(N=[128, 128, 128], params=dict(P1=1), p2p=1)], tmp_path)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layout", default="zyx")
     ap.add_argument("--t1", type=int, default=-1, help="x-tile thickness (default: the library's)")
     ap.add_argument("--t2", type=int, default=-1, help="z-chunk thickness (default: the library's)")
+    ap.add_argument("--touch", type=int, default=0, help="1: the first transform really fills the receive volumes (see the transport below)")
     ap.add_argument("--variants", default="", help="kernel variants vx,vy,vz (offt_hip_set_variant; 200 + id = column-pair variant id)")
     args = ap.parse_args()
     os.environ.setdefault("OFFT_TEST_TRANSPORT_NOSYNC", "1")  # the no-op exchange needs no host synchronisation
@@ -35,7 +36,21 @@ def main():
     import cpu_world
     from offt_amd import api
     L = cpu_world.test_lib()
-    cb = cpu_world.A2A_CB(lambda *a: 0)  # the exchange moves nothing
+    # the exchange moves nothing -- except, with --touch, during the FIRST transform, when every receive block is really
+    # written (device-to-device from the matching send block).  Without that the receive volume stays memory nobody has
+    # ever stored to, and reads of such memory are served faster than reads of real data: K2, and through the Infinity
+    # Cache K3, then look 10-15 % better than they are (profiles/r03_rehearse_touch.txt)
+    state = {"calls": 0, "touch": args.touch}
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def transport(which, npeers, peer, sendp, sendbytes, recvp, recvbytes):
+        if state["touch"]:
+            for a in range(npeers):
+                if recvbytes[a] and sendbytes[a] >= recvbytes[a]:
+                    hip.hipMemcpy(recvp[a], sendp[a], recvbytes[a], 3)
+        return 0
+    cb = cpu_world.A2A_CB(transport)
     L.offt_hip_test_set_transport(C.cast(cb, C.c_void_p), 0, args.ranks)
     prec = api.F64 if args.dtype == "f64" else api.F32
     esz = 16 if prec == api.F64 else 8
@@ -57,6 +72,9 @@ def main():
     L.offt_hip_fill_input(po, dev.data_ptr(), 1)
     L.offt_hip_set_output_scale(po, 2.0 ** -16)
     best = None
+    if args.touch:
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())  # every receive block written once
+        state["touch"] = False
     for _ in range(args.reps):
         api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
         t = (C.c_double * 3)()
