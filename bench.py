@@ -216,7 +216,8 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 def roofline_block(pass_s, paired, multi, esz, E, world, dt_step, dev_s, traffic_lookup=None):
     """roofline of the dominant kernel.  pass_s = device seconds of the z, y, x passes of one transform (events on the
-    plan's stream); `paired` = the y and x launches alternate over groups of planes, so only their SUM was measured."""
+    plan's stream); `paired` = 0, or the two passes (bits: 1 = z, 2 = y, 4 = x; offt_hip_last_passes_paired) whose launches
+    alternate over groups of planes, so that only their SUM was measured."""
     names = ["z", "y", "x"]
     alg_launch = 2.0 * esz * E / world
     if multi:
@@ -227,13 +228,16 @@ def roofline_block(pass_s, paired, multi, esz, E, world, dt_step, dev_s, traffic
                    "exchange-wait + K2 + K3 (z-chunks)": round(pass_s[2] * 1e3, 4)}
     elif paired:
         # the pair's launches interleave: each of the two moves 2*S*E bytes, the slower one is not known separately, so the
-        # pair enters with HALF its time per launch-equivalent -- the z pass, a single launch, is named when it is slower
-        pair = pass_s[1] + pass_s[2]
-        if pass_s[0] >= 0.5 * pair:
-            k, kdur, kname = 0, pass_s[0], "fft_panel_k (z-axis pass)"
+        # pair enters with HALF its time per launch-equivalent -- the third pass, a single launch, is named when it is slower
+        ab = [i for i in range(3) if paired >> i & 1]
+        one = [i for i in range(3) if not paired >> i & 1][0]
+        pair = pass_s[ab[0]] + pass_s[ab[1]]
+        if pass_s[one] >= 0.5 * pair:
+            k, kdur, kname = one, pass_s[one], f"fft_panel_k ({names[one]}-axis pass)"
         else:
-            k, kdur, kname = 1, 0.5 * pair, "fft_panel_k (y- and x-axis passes, alternating launches: half of the pair's time)"
-        pass_ms = {"z": round(pass_s[0] * 1e3, 4), "y+x (alternating launches, measured as a pair)": round(pair * 1e3, 4)}
+            k, kdur, kname = ab[0], 0.5 * pair, f"fft_panel_k ({names[ab[0]]}- and {names[ab[1]]}-axis passes, alternating launches: half of the pair's time)"
+        pass_ms = {names[one]: round(pass_s[one] * 1e3, 4),
+                   f"{names[ab[0]]}+{names[ab[1]]} (alternating launches, measured as a pair)": round(pair * 1e3, 4)}
     else:
         k = max(range(3), key=lambda i: pass_s[i])
         kdur, kname = pass_s[k], f"fft_panel_k ({names[k]}-axis pass)"
@@ -397,7 +401,7 @@ def rank_main(args):
     ms = dt / steps * 1e3
     value = flops * steps / dt / 1e9
     alg_bytes_transform = 6.0 * esz * E / world
-    paired = bool(L.offt_hip_last_passes_paired(po))
+    paired = int(L.offt_hip_last_passes_paired(po))
 
     def traffic_lookup(axis):
         if not (os.path.exists(TRAFFIC_JSON) and world == 1 and n == 1024 and prec == api.F64 and not multi):

@@ -63,19 +63,40 @@ int main(int argc, char **argv) {
     const char *idf = getenv("OFFT_ID_FILE");
     char id[OFFT_HIP_UNIQUE_ID_BYTES];
     if (!idf) { fprintf(stderr, "WORLD_SIZE > 1 needs OFFT_ID_FILE (or build the harness with MPI=1)\n"); return 2; }
+    /* The file is bound to THIS run: the id is followed by a nonce every rank of the run knows (OFFT_RUN_NONCE, else the
+     * launcher's MASTER_PORT / TORCHELASTIC_RUN_ID), and a reader accepts only a file that carries its own nonce -- a file
+     * left behind by an earlier run at the same path is ignored (the ranks would otherwise read a stale id at once and
+     * block in ncclCommInitRank, which has no time-out).  Without any of the three variables the path itself must be
+     * fresh per run (tools/launch.py makes one in a new temporary directory). */
+    char nonce[64];
+    memset(nonce, 0, sizeof nonce);
+    {
+      const char *nv = getenv("OFFT_RUN_NONCE");
+      if (!nv) nv = getenv("MASTER_PORT");
+      if (!nv) nv = getenv("TORCHELASTIC_RUN_ID");
+      if (nv) snprintf(nonce, sizeof nonce, "%s", nv);
+      else if (rank == 0) fprintf(stderr, "run-fft: no OFFT_RUN_NONCE / MASTER_PORT: %s must not exist from an earlier run\n", idf);
+    }
     if (rank == 0) {
       char tmp[4096];
       snprintf(tmp, sizeof tmp, "%s.tmp", idf);
       if (offt_hip_get_unique_id(id)) return 2;
       FILE *f = fopen(tmp, "wb");
-      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp); return 2; }
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fwrite(nonce, 1, sizeof nonce, f) != sizeof nonce) { fprintf(stderr, "cannot write %s\n", tmp); return 2; }
       fclose(f);
       if (rename(tmp, idf)) { fprintf(stderr, "cannot publish %s\n", idf); return 2; }
     } else {
-      FILE *f = NULL;
-      for (int tries = 0; tries < 6000 && !(f = fopen(idf, "rb")); tries++) usleep(10000); /* up to 60 s */
-      if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no RCCL id in %s\n", rank, idf); return 2; }
-      fclose(f);
+      int ok = 0;
+      for (int tries = 0; tries < 6000 && !ok; tries++) { /* up to 60 s */
+        char got[64];
+        FILE *f = fopen(idf, "rb");
+        if (f) {
+          ok = fread(id, 1, sizeof id, f) == sizeof id && fread(got, 1, sizeof got, f) == sizeof got && !memcmp(got, nonce, sizeof got);
+          fclose(f);
+        }
+        if (!ok) usleep(10000);
+      }
+      if (!ok) { fprintf(stderr, "rank %d: no RCCL id of this run (nonce \"%s\") in %s\n", rank, nonce, idf); return 2; }
     }
     if (offt_hip_set_world(rank, p, id, dev)) return 3;
   }

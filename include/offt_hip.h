@@ -105,7 +105,8 @@ long long offt_hip_local_bytes(const struct _offt_plan *po);
 double offt_hip_last_device_seconds(const struct _offt_plan *po);
 /* per-pass device seconds of the last execute: z, y, x passes (0 if fused away).  When two of the passes ran as
  * alternating launches over groups of planes (single rank: the y and x passes of the z-y-x layout), only their SUM was
- * measured and each of the two slots holds half of it: offt_hip_last_passes_paired() says so. */
+ * measured and each of the two slots holds half of it: offt_hip_last_passes_paired() returns 0, or the two slots as
+ * bits (1 = z, 2 = y, 4 = x). */
 void offt_hip_last_pass_seconds(const struct _offt_plan *po, double t[3]);
 int offt_hip_last_passes_paired(const struct _offt_plan *po);
 /* last error text ("" if none); errors also go to stderr, like the reference's

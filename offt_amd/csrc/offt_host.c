@@ -379,6 +379,7 @@ typedef struct hip_state {
   void *s_comm1, *s_comm2;
   void *ev0, *ev1, *evp[4];
   void *work; size_t work_elems; /* single path: transposed-output scratch */
+  void *work2;                   /* ... x-y-z output (S = 1): the second rotation's scratch */
   /* pipeline */
   int T, ntiles, ring;
   int slab_zyx;          /* p1 == 1 and z-y-x output: single-exchange slab schedule, see execute_slab() */
@@ -1012,6 +1013,7 @@ static void state_free(hip_state *st) {
   if (!st) return;
   const offt_backend *be = st->be;
   be->dfree(st->work);
+  be->dfree(st->work2);
   be->dfree(st->agree_d); free(st->agree_h);
   mesh_teardown(st);
   be->dfree(st->stage);
@@ -1127,6 +1129,13 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
       st->work_elems = (size_t)Nx * ((size_t)(Ny + st->wrow) * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
+    } else if (!(getenv("OFFT_S1_INPLACE") && atoi(getenv("OFFT_S1_INPLACE")))) {
+      /* x-y-z output: two scratch volumes for the rotating schedule of execute_single, W[y][z][x] and V[z][x][y]; without
+       * them (allocation failed, or OFFT_S1_INPLACE=1) the three passes run in place, two of them strided */
+      const size_t nzc = (size_t)(is_r2c ? Nz / 2 + 1 : Nz);
+      st->work = be->dmalloc((size_t)Ny * (nzc * Nx + (size_t)st->wpad) * st->esz);
+      st->work2 = be->dmalloc(nzc * ((size_t)Nx * Ny + (size_t)st->wpad) * st->esz);
+      if (!st->work || !st->work2) { be->dfree(st->work); be->dfree(st->work2); st->work = st->work2 = NULL; }
     }
   } else {
     st->t1_custom = custom_params && custom_params->v[_T1_] >= 0;
@@ -1567,7 +1576,12 @@ void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
 }
 double offt_hip_last_device_seconds(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->last_dev_s; }
-int offt_hip_last_passes_paired(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->yx_fused != 0; }
+/* 0, or the two timer slots (bit 0 = z, 1 = y, 2 = x) whose launches alternated and were measured as a pair */
+int offt_hip_last_passes_paired(const struct _offt_plan *po) {
+  const hip_state *st = (const hip_state *)po->hip_state;
+  if (!st->yx_fused) return 0;
+  return (1 << st->pass_slot[st->yx_fused - 1]) | (1 << st->pass_slot[st->yx_fused]);
+}
 void offt_hip_last_pass_seconds(const struct _offt_plan *po, double t[3]) {
   const hip_state *st = (const hip_state *)po->hip_state;
   t[0] = st->pass_s[0]; t[1] = st->pass_s[1]; t[2] = st->pass_s[2];
@@ -1596,8 +1610,50 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   const int S = po->params->v[_S_] != 0;
   const int zyx = !S && !(po->is_equalxy && c->M1 == c->M4);
 
-  if (S) {
-    /* x-y-z output == input layout: three in-place passes, strided along y and x */
+  int s1_rot = 0;
+  if (S && st->work && st->work2) {
+    /* x-y-z output == input layout, x outermost on both sides: an FFT along x that touched this layout directly would walk
+     * memory at a plane-sized stride (16 MiB at 1024^3: 56 % of the roofline, profiles/r02_layouts_zgroup.txt).  Instead
+     * every pass reads whole contiguous lines and rotates on its stores (128-B column segments at a pitch of one line),
+     * like the z-y-x schedule, with the x pass in the MIDDLE, between two scratch volumes:
+     *   P1  in[x][y][z] --FFTz--> W[y][z][x]    columns = 8 x-planes: eight lines gathered from eight planes
+     *   P2  W[y][z][x]  --FFTx--> V[z][x][y]    columns = 8 y
+     *   P3  V[z][x][y]  --FFTy--> out[x][y][z]  columns = 8 z
+     * (the inverse runs y, x, z with loads and stores swapped).  Three contig-in / strided-out passes. */
+    const long long wy = (long long)Nz * Nx + st->wpad;  /* W: y-plane pitch */
+    const long long vz = (long long)Nx * Ny + st->wpad;  /* V: z-plane pitch */
+    void *V = st->work2;
+    s1_rot = 1;
+    desc_init(&d[0], st, Nzf, dir, 2);
+    d[0].real_input = po->is_r2c;
+    desc_init(&d[1], st, Nx, dir, 0);
+    desc_init(&d[2], st, Ny, dir, 1);
+    d[0].ncols = Nx; d[0].nb1 = Ny;
+    d[1].ncols = Ny; d[1].nb1 = Nz;
+    d[2].ncols = Nz; d[2].nb1 = Nx;
+    if (dir < 0) {
+      d[0].in_axis_stride = 1; d[0].in_col_stride = is0; d[0].in_b1_stride = is1; d[0].in_contig = 1;
+      d[0].out_axis_stride = Nx; d[0].out_col_stride = 1; d[0].out_b1_stride = wy; d[0].out_contig = 0;
+      d[1].in_axis_stride = 1; d[1].in_col_stride = wy; d[1].in_b1_stride = Nx; d[1].in_contig = 1;
+      d[1].out_axis_stride = Ny; d[1].out_col_stride = 1; d[1].out_b1_stride = vz; d[1].out_contig = 0;
+      d[2].in_axis_stride = 1; d[2].in_col_stride = vz; d[2].in_b1_stride = Ny; d[2].in_contig = 1;
+      d[2].out_axis_stride = os1; d[2].out_col_stride = os2; d[2].out_b1_stride = os0; d[2].out_contig = 0;
+      src[0] = data; dst[0] = W; src[1] = W; dst[1] = V; src[2] = V; dst[2] = data;
+      slot[0] = 0; slot[1] = 2; slot[2] = 1;
+    } else {
+      offt_pass_desc t;
+      d[2].in_axis_stride = os1; d[2].in_col_stride = os2; d[2].in_b1_stride = os0; d[2].in_contig = 0;
+      d[2].out_axis_stride = 1; d[2].out_col_stride = vz; d[2].out_b1_stride = Ny; d[2].out_contig = 1;
+      d[1].in_axis_stride = Ny; d[1].in_col_stride = 1; d[1].in_b1_stride = vz; d[1].in_contig = 0;
+      d[1].out_axis_stride = 1; d[1].out_col_stride = wy; d[1].out_b1_stride = Nx; d[1].out_contig = 1;
+      d[0].in_axis_stride = Nx; d[0].in_col_stride = 1; d[0].in_b1_stride = wy; d[0].in_contig = 0;
+      d[0].out_axis_stride = 1; d[0].out_col_stride = is0; d[0].out_b1_stride = is1; d[0].out_contig = 1;
+      t = d[0]; d[0] = d[2]; d[2] = t; /* launch order y, x, z */
+      src[0] = data; dst[0] = V; src[1] = V; dst[1] = W; src[2] = W; dst[2] = data;
+      slot[0] = 1; slot[1] = 2; slot[2] = 0;
+    }
+  } else if (S) {
+    /* x-y-z output == input layout without scratch: three in-place passes, strided along y and x */
     desc_init(&d[0], st, Nzf, dir, 2);
     d[0].real_input = po->is_r2c;
     d[0].ncols = Ny; d[0].nb1 = Nx;
@@ -1716,8 +1772,12 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   double plane_elems = 0.0;
   int len_a = 0, len_b = 0;   /* their line lengths */
   if (zyx) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
+  /* rotating x-y-z schedule, forward: P1 writes W[y][z][x] y-plane by y-plane, P2 takes y-planes as its COLUMNS (8 lines out
+   * of 8 planes): the pair shares groups of y-planes, the consumer sliced along its column dimension */
+  int cons_cols = 0;
+  if (s1_rot) { if (dir < 0) { ia = 0; cnt = Ny; plane_elems = (double)Nz * Nx; len_a = Nzf; len_b = Nx; cons_cols = 1; } }
   else if (S || dir < 0) { ia = 0; cnt = Nx; plane_elems = (double)Ny * Nz; len_a = Nzf; len_b = Ny; }
-  if (ia >= 0 && d[ia].nb1 == cnt && d[ia + 1].nb1 == cnt && !d[ia].real_input &&
+  if (ia >= 0 && d[ia].nb1 == cnt && (cons_cols ? d[ia + 1].ncols == cnt : d[ia + 1].nb1 == cnt) && !d[ia].real_input &&
       (st->opt.zgroup_mib >= 0 || (len_a <= 1024 && len_b <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
     const int ib = ia + 1;
     const int group_mib = st->opt.zgroup_mib >= 0 ? st->opt.zgroup_mib : 256;
@@ -1727,6 +1787,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
       if (ng > cnt) ng = cnt;
+      if (cons_cols && ng >= 8) ng -= ng % 8; /* whole 8-column panels */
       /* the consumer of a group runs on a second stream behind its producer, so that the next group's producer fills the
        * CUs its last workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
       int aux = two_streams && ng < cnt;
@@ -1744,12 +1805,13 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
       for (int z0 = 0; z0 < cnt; z0 += ng, k++) {
         const int g = cnt - z0 < ng ? cnt - z0 : ng;
         offt_pass_desc da = d[ia], db = d[ib];
-        da.nb1 = g; db.nb1 = g;
+        da.nb1 = g;
+        if (cons_cols) db.ncols = g; else db.nb1 = g;
         da.out_keep = 1;
         const char *sa = (const char *)src[ia] + (size_t)z0 * (size_t)da.in_b1_stride * st->esz;
         char *oa = (char *)dst[ia] + (size_t)z0 * (size_t)da.out_b1_stride * st->esz;
-        const char *sb = (const char *)src[ib] + (size_t)z0 * (size_t)db.in_b1_stride * st->esz;
-        char *ob = (char *)dst[ib] + (size_t)z0 * (size_t)db.out_b1_stride * st->esz;
+        const char *sb = (const char *)src[ib] + (size_t)z0 * (size_t)(cons_cols ? db.in_col_stride : db.in_b1_stride) * st->esz;
+        char *ob = (char *)dst[ib] + (size_t)z0 * (size_t)(cons_cols ? db.out_col_stride : db.out_b1_stride) * st->esz;
         if (be->pass(&da, sa, oa, s)) return -1;
         if (aux) {
           be->event_record(st->ev_aux[k & 3], s);

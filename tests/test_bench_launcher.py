@@ -79,17 +79,19 @@ def test_line_blocks_are_self_consistent_across_n():
     import bench
     E, esz = 1024.0 ** 3, 16
     # N = 1, y and x launches alternating: only z and the pair's sum exist
-    r = bench.roofline_block([5.8e-3, 5.3e-3, 5.3e-3], True, False, esz, E, 1, 16.4e-3, 16.4e-3, lambda axis: 34.365e9 if axis == "z" else None)
+    r = bench.roofline_block([5.8e-3, 5.3e-3, 5.3e-3], 6, False, esz, E, 1, 16.4e-3, 16.4e-3, lambda axis: 34.365e9 if axis == "z" else None)
     assert set(r["pass_ms"]) == {"z", "y+x (alternating launches, measured as a pair)"}
     assert abs(r["pass_ms"]["y+x (alternating launches, measured as a pair)"] - 10.6) < 1e-9
     assert r["kernel"].startswith("fft_panel_k (z-axis pass)") and abs(r["frac"] - 2 * esz * E / 5.8e-3 / 8e12) < 1e-3
     assert r["traffic"] == 34.365e9 and "NOT measured in this run" in r["traffic_source"]
     assert r["frac"] <= 1.0 and r["avg_launch_ms"] <= 16.4
     # N = 1, three plain launches: three separate times, the slowest is named
-    r = bench.roofline_block([5.0e-3, 6.0e-3, 5.5e-3], False, False, esz, E, 1, 16.6e-3, 16.5e-3)
+    r = bench.roofline_block([5.0e-3, 6.0e-3, 5.5e-3], 0, False, esz, E, 1, 16.6e-3, 16.5e-3)
     assert set(r["pass_ms"]) == {"z", "y", "x"} and "y-axis" in r["kernel"] and r["traffic"] is None and r["traffic_source"] is None
     # N = 8: K1 phase and the chunked phase, per-rank bytes
-    r = bench.roofline_block([0.8e-3, 0.0, 4.0e-3], False, True, esz, E, 8, 4.9e-3, 4.8e-3)
+    r = bench.roofline_block([5.4e-3, 6.0e-3, 5.4e-3], 5, False, esz, E, 1, 16.9e-3, 16.8e-3)   # x-y-z layout: z and x alternate
+    assert set(r["pass_ms"]) == {"y", "z+x (alternating launches, measured as a pair)"} and "y-axis" in r["kernel"]
+    r = bench.roofline_block([0.8e-3, 0.0, 4.0e-3], 0, True, esz, E, 8, 4.9e-3, 4.8e-3)
     assert "K1" in r["kernel"] and r["alg_bytes_per_launch"] == 2 * esz * E / 8 and len(r["pass_ms"]) == 2
     # xGMI block: 8 ranks on 7 links; a group of one (the one-GPU rehearsal) has none
     x = bench.xgmi_block(8, esz, E, 8, 4.0e-3)

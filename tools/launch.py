@@ -11,6 +11,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +28,7 @@ def main():
     if not cmd:
         ap.error("no command")
     os.environ["OFFT_ID_FILE"] = os.path.join(tempfile.mkdtemp(prefix="offt_id_"), "rccl_id")
+    os.environ["OFFT_RUN_NONCE"] = "%d-%d" % (os.getpid(), int(time.time() * 1e6))  # run-fft accepts only this run's id file
 
     class Args:
         gpus = a.nproc
