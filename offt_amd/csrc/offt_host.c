@@ -1129,9 +1129,14 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
       st->work_elems = (size_t)Nx * ((size_t)(Ny + st->wrow) * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
-    } else if (!(getenv("OFFT_S1_INPLACE") && atoi(getenv("OFFT_S1_INPLACE")))) {
-      /* x-y-z output: two scratch volumes for the rotating schedule of execute_single, W[y][z][x] and V[z][x][y]; without
-       * them (allocation failed, or OFFT_S1_INPLACE=1) the three passes run in place, two of them strided */
+    } else if (getenv("OFFT_S1_INPLACE") ? !atoi(getenv("OFFT_S1_INPLACE"))
+                                         : ((size_t)Ny * (size_t)(is_r2c ? Nz / 2 + 1 : Nz) * st->esz) % ((size_t)1 << 20) == 0) {
+      /* x-y-z output: two scratch volumes for the rotating schedule of execute_single, W[y][z][x] and V[z][x][y].  Used when
+       * an x-plane is a whole number of MiB -- then the in-place x pass, whose lines step through memory plane by plane,
+       * keeps hitting the same HBM channels (1024^3 f64: 7.8 ms = 55 % against 5.9 ms; 512^3: 0.95 against 0.72 ms), while
+       * at other pitches (768^3: 9 MiB planes) the in-place passes are as fast and need no scratch
+       * (profiles/r03_layouts.txt).  OFFT_S1_INPLACE=1 / 0 forces either.  Without the volumes (allocation failed) the
+       * three passes run in place. */
       const size_t nzc = (size_t)(is_r2c ? Nz / 2 + 1 : Nz);
       st->work = be->dmalloc((size_t)Ny * (nzc * Nx + (size_t)st->wpad) * st->esz);
       st->work2 = be->dmalloc(nzc * ((size_t)Nx * Ny + (size_t)st->wpad) * st->esz);
@@ -1772,12 +1777,12 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   double plane_elems = 0.0;
   int len_a = 0, len_b = 0;   /* their line lengths */
   if (zyx) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
-  /* rotating x-y-z schedule, forward: P1 writes W[y][z][x] y-plane by y-plane, P2 takes y-planes as its COLUMNS (8 lines out
-   * of 8 planes): the pair shares groups of y-planes, the consumer sliced along its column dimension */
-  int cons_cols = 0;
-  if (s1_rot) { if (dir < 0) { ia = 0; cnt = Ny; plane_elems = (double)Nz * Nx; len_a = Nzf; len_b = Nx; cons_cols = 1; } }
+  /* (the rotating x-y-z schedule runs its three launches plainly: P1 and P2 do share y-planes of W, but alternating them
+   * over groups of planes -- the consumer sliced along its columns -- came out SLOWER, 17.9 against 17.4 ms at 1024^3 f64,
+   * profiles/r03_layouts.txt) */
+  else if (s1_rot) ia = -1;
   else if (S || dir < 0) { ia = 0; cnt = Nx; plane_elems = (double)Ny * Nz; len_a = Nzf; len_b = Ny; }
-  if (ia >= 0 && d[ia].nb1 == cnt && (cons_cols ? d[ia + 1].ncols == cnt : d[ia + 1].nb1 == cnt) && !d[ia].real_input &&
+  if (ia >= 0 && d[ia].nb1 == cnt && d[ia + 1].nb1 == cnt && !d[ia].real_input &&
       (st->opt.zgroup_mib >= 0 || (len_a <= 1024 && len_b <= 1024 && (g_backend || offt_hipk_keeps_output(&d[ia]))))) {
     const int ib = ia + 1;
     const int group_mib = st->opt.zgroup_mib >= 0 ? st->opt.zgroup_mib : 256;
@@ -1787,7 +1792,6 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
     int ng = group_mib > 0 ? (int)((double)group_mib / plane_mib) : 0;
     if (ng >= 1) {
       if (ng > cnt) ng = cnt;
-      if (cons_cols && ng >= 8) ng -= ng % 8; /* whole 8-column panels */
       /* the consumer of a group runs on a second stream behind its producer, so that the next group's producer fills the
        * CUs its last workgroups leave idle: groups can be small (good for the cache) without paying a launch tail each */
       int aux = two_streams && ng < cnt;
@@ -1805,13 +1809,12 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
       for (int z0 = 0; z0 < cnt; z0 += ng, k++) {
         const int g = cnt - z0 < ng ? cnt - z0 : ng;
         offt_pass_desc da = d[ia], db = d[ib];
-        da.nb1 = g;
-        if (cons_cols) db.ncols = g; else db.nb1 = g;
+        da.nb1 = g; db.nb1 = g;
         da.out_keep = 1;
         const char *sa = (const char *)src[ia] + (size_t)z0 * (size_t)da.in_b1_stride * st->esz;
         char *oa = (char *)dst[ia] + (size_t)z0 * (size_t)da.out_b1_stride * st->esz;
-        const char *sb = (const char *)src[ib] + (size_t)z0 * (size_t)(cons_cols ? db.in_col_stride : db.in_b1_stride) * st->esz;
-        char *ob = (char *)dst[ib] + (size_t)z0 * (size_t)(cons_cols ? db.out_col_stride : db.out_b1_stride) * st->esz;
+        const char *sb = (const char *)src[ib] + (size_t)z0 * (size_t)db.in_b1_stride * st->esz;
+        char *ob = (char *)dst[ib] + (size_t)z0 * (size_t)db.out_b1_stride * st->esz;
         if (be->pass(&da, sa, oa, s)) return -1;
         if (aux) {
           be->event_record(st->ev_aux[k & 3], s);
