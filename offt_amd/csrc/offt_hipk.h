@@ -71,6 +71,9 @@ int offt_hipk_keeps_output(const offt_pass_desc *d);
 /* 1 if a register/LDS Stockham panel kernel exists for (n, precision): powers of two up to 4096
  * and the swept 2^a 3^b 5^c lengths; 0 if the pass will run on the any-length kernel.        */
 int offt_hipk_has_fast_path(int n, int precision);
+/* 1 if lines of n points have no single-launch kernel and run as a four-step decomposition n = n1 n2 (two sub-passes and a
+ * twiddle sweep through scratch; complex input only).  Valid after offt_hipk_prepare(n, precision).                    */
+int offt_hipk_is_four_step(int n, int precision);
 /* number of sweep variants registered for (n, precision, in_contig, out_contig) */
 int offt_hipk_variant_count(int n, int precision);
 /* human-readable description of a variant, for sweep logs                      */

@@ -808,6 +808,97 @@ extern "C" int offt_hipk_keeps_output(const offt_pass_desc *d) {
 
 int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
+// ---------------------------------------------------------------------------
+// Four-step decomposition: lines no single kernel takes.
+//
+// FFTW plans any length (offt-compute.c:335-341, 416-425); the panel kernels end at 4096 points (8192 with one column per
+// workgroup), the any-length kernel where two images of a line fill the LDS (5120 double / 10240 single points).  A longer
+// line of n = n1 n2 points is transformed as  X[k1 + n1 k2] = sum_{j2} w_n^(j2 k1) [ sum_{j1} x[j1 n2 + j2] w_n1^(j1 k1) ] w_n2^(j2 k2):
+//   A  n2 x (n1-point FFTs over j1)   -- any kernel of the library, reading the caller's layout (splits, block tables)
+//   T  times w_n^(j2 k1)              -- the exact full-wave table of n; j2 k1 < n, so no reduction
+//   C  n1 x (n2-point FFTs over j2)   -- any kernel, writing the caller's layout
+// through a dense scratch S[column][k1][j2] (j2 contiguous).  A side whose unit-stride dimension is the axis takes the
+// j2 / k1 index as the sub-pass's columns; a side whose columns are unit-stride keeps them as columns -- every access
+// stays a 128-B segment.  For a strided-in pass step A writes S'[k1][j2][column] and T transposes on the way.
+// Three sweeps over the data instead of one: a correctness net with decent bandwidth, not a tuned path.
+// ---------------------------------------------------------------------------
+struct FourStep { int n1 = 0, n2 = 0; };
+std::mutex g_four_mu;
+std::map<std::pair<int, int>, FourStep> g_four;
+struct Scratch { void *p[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
+std::map<void *, Scratch> g_four_scratch;  // per stream
+
+bool four_lookup(int n, int prec, FourStep *out) {
+  std::lock_guard<std::mutex> lk(g_four_mu);
+  auto it = g_four.find(std::make_pair(n, prec));
+  if (it == g_four.end()) return false;
+  if (out) *out = it->second;
+  return true;
+}
+
+// a single launch can transform lines of n points: a panel kernel, the Bluestein kernel, or the any-length kernel
+bool direct_ok(int n, int prec) {
+  if (find_variant(n, prec, true, true, -1)) return true;
+  BlueTab bt;
+  if (blue_lookup(n, prec, &bt)) return true;
+  const size_t esz = prec == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  return 2 * (size_t)n * esz <= (size_t)160 * 1024;
+}
+
+void *four_scratch(void *stream, int which, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_four_mu);
+  Scratch &sc = g_four_scratch[stream];
+  if (sc.bytes[which] < bytes) {
+    if (sc.p[which]) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(sc.p[which]); }
+    sc.p[which] = nullptr; sc.bytes[which] = 0;
+    if (hipMalloc(&sc.p[which], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    sc.bytes[which] = bytes;
+  }
+  return sc.p[which];
+}
+
+// T, in place: S[q][k1][j2] *= w_n^(+-(k1 j2))
+template <typename V2>
+__global__ void __launch_bounds__(256) four_twiddle_k(V2 *s, const V2 *tw, long long total, int n1, int n2, int conj) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j2 = (int)(i % n2), k1 = (int)((i / n2) % n1);
+  const V2 w = tw[k1 * j2];
+  const V2 x = s[i];
+  const auto wy = conj ? -w.y : w.y;
+  V2 r;
+  r.x = x.x * w.x - x.y * wy;
+  r.y = x.x * wy + x.y * w.x;
+  s[i] = r;
+}
+// T for a strided-in pass: S'[b][m][c] (m = k1 n2 + j2 < n, c < cc) -> S[b][c][m] times w_n^(+-(k1 j2)), 32 x 32 tiles through LDS
+template <typename V2>
+__global__ void __launch_bounds__(256) four_twiddle_t_k(const V2 *sp, V2 *s, const V2 *tw, int n, int cc, int n2, int conj) {
+  __shared__ V2 tile[32][33];
+  const long long b = blockIdx.z;
+  const int m0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int m = m0 + r, c = c0 + tx;
+    if (m < n && c < cc) tile[r][tx] = sp[(b * n + m) * cc + c];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, m = m0 + tx;
+    if (m < n && c < cc) {
+      const V2 x = tile[tx][r];
+      const int k1 = m / n2, j2 = m - k1 * n2;
+      const V2 w = tw[k1 * j2];
+      const auto wy = conj ? -w.y : w.y;
+      V2 o;
+      o.x = x.x * w.x - x.y * wy;
+      o.y = x.x * wy + x.y * w.x;
+      s[(b * cc + c) * n + m] = o;
+    }
+  }
+}
+
+int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const FourStep &fs);
+
 }  // namespace
 
 extern "C" {
@@ -816,6 +907,12 @@ const char *offt_hipk_last_error(void) { return g_err; }
 
 int offt_hipk_has_fast_path(int n, int precision) {
   return find_variant(n, precision, true, true, -1) != nullptr;
+}
+
+/* 1 if lines of n points run as a four-step decomposition (no single launch takes them): complex input only */
+int offt_hipk_is_four_step(int n, int precision) {
+  const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  return four_lookup(n, precision, nullptr) && !find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024;
 }
 
 int offt_hipk_variant_count(int n, int precision) {
@@ -866,12 +963,41 @@ int offt_hipk_prepare(int n, int precision) {
       g_blue[std::make_pair(n, precision)] = bt;
     }
   }
-  // a length neither a panel kernel nor the any-length kernel (two ping-pong images of one line in LDS) can take is
-  // refused HERE, at plan time: offt_3d_init returns NULL instead of every execute failing
+  // a length no single launch takes (no panel kernel, and two images of a line do not fit the LDS of the any-length
+  // kernel) is split n = n1 n2 for the four-step path above; 8192 has a register kernel, but with one column per
+  // workgroup: its strided flavours go the four-step way as well.  Only a length without such a split -- a prime, or a
+  // prime factor too large itself -- is refused, HERE, at plan time: offt_3d_init returns NULL instead of every execute failing
   const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
-  if (!find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024) {
-    snprintf(g_err, sizeof g_err, "no kernel for lines of %d %s points: no register kernel, and the any-length kernel holds at most %zu",
-             n, precision == OFFT_PREC_F64 ? "double-complex" : "single-complex", (size_t)160 * 1024 / (2 * esz));
+  const bool no_direct = !find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024;
+  static const bool four_on = !(getenv("OFFT_FOURSTEP") && atoi(getenv("OFFT_FOURSTEP")) == 0);
+  if ((no_direct || n == 8192) && four_on && !four_lookup(n, precision, nullptr)) {
+    int best1 = 0;
+    double best_score = 1e30;
+    for (int n1 = 2; (long long)n1 * n1 <= n; ++n1) {
+      if (n % n1) continue;
+      const int n2 = n / n1;
+      // both factors need a kernel of their own: prefer precompiled register kernels and a balanced split (candidates are
+      // only looked up here, not prepared -- preparing may compile a plan-time kernel, seconds each)
+      const bool f1 = find_variant(n1, precision, true, true, -1) != nullptr, f2 = find_variant(n2, precision, true, true, -1) != nullptr;
+      if ((!f1 && 2 * (size_t)n1 * esz > (size_t)160 * 1024) || (!f2 && 2 * (size_t)n2 * esz > (size_t)160 * 1024)) continue;
+      double score = std::log((double)n2 / (double)n1);
+      if (!f1) score += 4.0;
+      if (!f2) score += 4.0;
+      if (score < best_score) { best_score = score; best1 = n1; }
+    }
+    if (best1 && (offt_hipk_prepare(best1, precision) || offt_hipk_prepare(n / best1, precision) ||
+                  !direct_ok(best1, precision) || !direct_ok(n / best1, precision)))
+      best1 = 0;
+    if (best1) {
+      std::lock_guard<std::mutex> lk(g_four_mu);
+      FourStep fs; fs.n1 = best1; fs.n2 = n / best1;
+      g_four[std::make_pair(n, precision)] = fs;
+    }
+  }
+  if (no_direct && !four_lookup(n, precision, nullptr)) {
+    snprintf(g_err, sizeof g_err, "no kernel for lines of %d %s points: no register kernel, the any-length kernel holds at most %zu, and %d has no "
+             "factorisation n1 n2 into lengths that have one", n, precision == OFFT_PREC_F64 ? "double-complex" : "single-complex",
+             (size_t)160 * 1024 / (2 * esz), n);
     return -1;
   }
   return 0;
@@ -886,6 +1012,14 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     return 0;
   Tables tb;
   if (get_tables(d->n, d->precision, tb, false)) return -1;
+  {
+    FourStep fs;
+    if (four_lookup(d->n, d->precision, &fs)) {
+      const size_t esz4 = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+      const bool no_direct = !find_variant(d->n, d->precision, true, true, -1) && 2 * (size_t)d->n * esz4 > (size_t)160 * 1024;
+      if (no_direct || !(d->in_contig && d->out_contig)) return four_pass(d, in, out, stream, fs);
+    }
+  }
   Variant *v = pick_variant(d);
   if (v && v->prec == OFFT_PREC_F32_PAIR &&
       ((!d->in_contig && ((uintptr_t)in & 15)) || (!d->out_contig && ((uintptr_t)out & 15))))
@@ -1019,6 +1153,100 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   HIPK_CHECK(hipGetLastError());
   return 0;
 }
+
+}  // extern "C"
+
+namespace {
+int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const FourStep &fs) {
+  const int N = d->n, N1 = fs.n1, N2 = fs.n2;
+  const size_t esz = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  if (d->real_input) { snprintf(g_err, sizeof g_err, "four-step path: real-input lines of %d points are not supported", N); return -1; }
+  // a per-peer split must cut the axis where the decomposition can follow it: whole runs of n2 inputs / n1 outputs
+  if ((d->in_split && (d->in_split_nfloor || d->in_split % N2)) || (d->out_split && (d->out_split_nfloor || d->out_split % N1))) {
+    snprintf(g_err, sizeof g_err, "four-step path (%d = %d x %d): per-peer blocks of %d / %d points do not fit the decomposition", N, N1, N2,
+             d->in_split, d->out_split);
+    return -1;
+  }
+  Tables tb;
+  if (get_tables(N, d->precision, tb, false)) return -1;
+  const bool inL = d->in_contig != 0, outL = d->out_contig != 0;
+  // columns per chunk: whole rows of the caller's column dimension, as many b1 entries as fit 256 MiB of scratch
+  const size_t cap = ((size_t)256 << 20) / esz;
+  int cc = d->ncols, cb1 = d->nb1;
+  if ((size_t)cc * N > cap) { cc = (int)(cap / N); if (cc < 1) cc = 1; cb1 = 1; }
+  else { const size_t fit = cap / ((size_t)cc * N); if ((size_t)cb1 > fit) cb1 = (int)(fit < 1 ? 1 : fit); }
+  const size_t sbytes = (size_t)cc * cb1 * N * esz;
+  char *S = (char *)four_scratch(stream, 0, sbytes);
+  char *Sp = inL ? nullptr : (char *)four_scratch(stream, 1, sbytes);
+  if (!S || (!inL && !Sp)) { snprintf(g_err, sizeof g_err, "four-step path: cannot allocate %zu bytes of scratch", sbytes); return -1; }
+  for (int b2 = 0; b2 < d->nb2; ++b2)
+    for (int b10 = 0; b10 < d->nb1; b10 += cb1)
+      for (int c0 = 0; c0 < d->ncols; c0 += cc) {
+        const int nb = d->nb1 - b10 < cb1 ? d->nb1 - b10 : cb1, nc = d->ncols - c0 < cc ? d->ncols - c0 : cc;
+        const char *pin = (const char *)in + ((long long)b2 * d->in_b2_stride + (long long)b10 * d->in_b1_stride + (long long)c0 * d->in_col_stride) * (long long)esz;
+        char *pout = (char *)out + ((long long)b2 * d->out_b2_stride + (long long)b10 * d->out_b1_stride + (long long)c0 * d->out_col_stride) * (long long)esz;
+        // ---- A: n1-point transforms over j1 (input index j1 n2 + j2) ----
+        offt_pass_desc a;
+        memset(&a, 0, sizeof a);
+        a.n = N1; a.precision = d->precision; a.direction = d->direction; a.variant = -1; a.scale = 1.0; a.no_pairs = d->no_pairs;
+        a.in_axis_stride = (long long)N2 * d->in_axis_stride;
+        if (d->in_split) { a.in_split = d->in_split / N2; a.in_block_stride = d->in_block_stride; a.in_block_tab = d->in_block_tab; }
+        a.in_contig = 0; a.out_contig = 0;
+        if (inL) {  // the axis is the unit-stride dimension: j2 becomes the column dimension
+          a.ncols = N2; a.in_col_stride = d->in_axis_stride;
+          a.nb1 = nc; a.in_b1_stride = d->in_col_stride;
+          a.nb2 = nb; a.in_b2_stride = d->in_b1_stride;
+          a.out_axis_stride = N2; a.out_col_stride = 1; a.out_b1_stride = N; a.out_b2_stride = (long long)N * nc;  // S[q][k1][j2]
+          if (offt_hipk_fft_pass(&a, pin, S, stream)) return -1;
+        } else {    // the caller's columns are the unit-stride dimension and stay the columns: S'[b][k1][j2][c]
+          a.ncols = nc; a.in_col_stride = d->in_col_stride;
+          a.nb1 = N2; a.in_b1_stride = d->in_axis_stride;
+          a.nb2 = nb; a.in_b2_stride = d->in_b1_stride;
+          a.out_axis_stride = (long long)N2 * nc; a.out_col_stride = 1; a.out_b1_stride = nc; a.out_b2_stride = (long long)N * nc;
+          if (offt_hipk_fft_pass(&a, pin, Sp, stream)) return -1;
+        }
+        // ---- T: twiddles w_n^(j2 k1) (and the transposition S' -> S) ----
+        (void)hipGetLastError();
+        const int conj = d->direction > 0;
+        if (inL) {
+          const long long total = (long long)nc * nb * N;
+          const unsigned blocks = (unsigned)((total + 255) / 256);
+          if (d->precision == OFFT_PREC_F64)
+            hipLaunchKernelGGL(four_twiddle_k<double2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double2 *)S, (const double2 *)tb.full, total, N1, N2, conj);
+          else
+            hipLaunchKernelGGL(four_twiddle_k<float2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float2 *)S, (const float2 *)tb.full, total, N1, N2, conj);
+        } else {
+          const dim3 grid((unsigned)((nc + 31) / 32), (unsigned)((N + 31) / 32), (unsigned)nb);
+          if (d->precision == OFFT_PREC_F64)
+            hipLaunchKernelGGL(four_twiddle_t_k<double2>, grid, dim3(256), 0, (hipStream_t)stream, (const double2 *)Sp, (double2 *)S, (const double2 *)tb.full, N, nc, N2, conj);
+          else
+            hipLaunchKernelGGL(four_twiddle_t_k<float2>, grid, dim3(256), 0, (hipStream_t)stream, (const float2 *)Sp, (float2 *)S, (const float2 *)tb.full, N, nc, N2, conj);
+        }
+        HIPK_CHECK(hipGetLastError());
+        // ---- C: n2-point transforms over j2, output index k1 + n1 k2 ----
+        offt_pass_desc c;
+        memset(&c, 0, sizeof c);
+        c.n = N2; c.precision = d->precision; c.direction = d->direction; c.variant = -1; c.scale = d->scale; c.no_pairs = d->no_pairs;
+        c.out_keep = d->out_keep;
+        c.in_axis_stride = 1; c.in_contig = 1; c.out_contig = 0;
+        c.out_axis_stride = (long long)N1 * d->out_axis_stride;
+        if (d->out_split) { c.out_split = d->out_split / N1; c.out_block_stride = d->out_block_stride; c.out_block_tab = d->out_block_tab; }
+        if (outL) {  // k1 becomes the column dimension of the output
+          c.ncols = N1; c.in_col_stride = N2; c.out_col_stride = d->out_axis_stride;
+          c.nb1 = nc; c.in_b1_stride = N; c.out_b1_stride = d->out_col_stride;
+          c.nb2 = nb; c.in_b2_stride = (long long)N * nc; c.out_b2_stride = d->out_b1_stride;
+        } else {     // the caller's columns stay the columns
+          c.ncols = nc; c.in_col_stride = N; c.out_col_stride = d->out_col_stride;
+          c.nb1 = N1; c.in_b1_stride = N2; c.out_b1_stride = d->out_axis_stride;
+          c.nb2 = nb; c.in_b2_stride = (long long)N * nc; c.out_b2_stride = d->out_b1_stride;
+        }
+        if (offt_hipk_fft_pass(&c, S, pout, stream)) return -1;
+      }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
 
 // ---- flags of the direct-store exchange (offt_hipk.h) ----
 namespace {

@@ -57,3 +57,18 @@ def gpu_fft(shape, field=None, is_equalxy=0, precision=api.F64, is_r2c=0, **para
 
 def rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def gpu_roundtrip(shape, precision=api.F64, is_equalxy=0, **params):
+    """forward, then the inverse on the result: rel-L2 distance of (result / N) from the input block"""
+    field = O.hash_field(*shape)
+    po = api.offt_3d_init(*shape, custom_params=api.make_params(**params), is_equalxy=is_equalxy, precision=precision)
+    try:
+        dev, idx = make_input(po, field, precision)
+        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+        ct = np.complex128 if precision == api.F64 else np.complex64
+        back = dev.cpu().numpy().view(ct)[idx].reshape(shape) / np.prod(shape)
+        return rel(back, field)
+    finally:
+        api.offt_3d_fin(po)

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import oracle_lib as O
-from gpu_util import gpu_fft, make_input, read_output, rel
+from gpu_util import gpu_fft, make_input, read_output, rel, gpu_roundtrip
 from offt_amd import api
 
 pytestmark = pytest.mark.gpu
@@ -355,12 +355,27 @@ def test_full_size_2048_single_precision_properties(built):
     assert abs(e_out / (2.0 * e_in) - 1.0) < 1e-5
 
 
-def test_lengths_no_kernel_takes_are_refused_at_plan_time(built):
-    """a line too long for every kernel (no register kernel, more than the any-length kernel's LDS) must fail in
-    offt_3d_init, not on every execute (the reference's FFTW takes any N; this library says so up front)"""
-    for shape, prec in (((8, 8, 6000), api.F64), ((16384, 4, 4), api.F64), ((4, 12000, 4), api.F32)):
+@pytest.mark.parametrize("shape,prec,kw", [((8, 8, 6000), api.F64, {}), ((16384, 4, 4), api.F64, {}), ((4, 12000, 4), api.F32, {}),
+                                           ((8, 6000, 8), api.F64, dict(S=1)), ((8, 8, 16384), api.F32, dict(S=1)),
+                                           ((8192, 8, 8), api.F64, {}), ((8, 8192, 8), api.F64, dict(S=1)), ((8, 8, 8192), api.F32, {})])
+def test_long_lines_four_step(built, shape, prec, kw):
+    """lines no single kernel takes (above 5120 double / 10240 single points; FFTW plans any N, offt-compute.c:335-341,
+    416-425) run as a four-step decomposition n = n1 n2 -- two sub-passes of the library's own kernels and a twiddle sweep
+    -- on every axis and in every pass flavour; 8192 has a one-column register kernel whose strided flavours go the same
+    way.  Forward against the oracle, inverse round trip."""
+    got, c = gpu_fft(shape, precision=prec, **kw)
+    want, _, _ = O.world_fft(*shape, 1, kind=1, **kw)
+    assert rel(got, want) < (TOL64 if prec == api.F64 else TOL32), (shape, kw)
+    back = gpu_roundtrip(shape, precision=prec, **kw)
+    assert back < (TOL64 if prec == api.F64 else TOL32)
+
+
+def test_lengths_without_any_kernel_are_refused_at_plan_time(built):
+    """what is left: a long PRIME line (no factorisation n1 n2 to decompose along) and long real-input lines must fail in
+    offt_3d_init, not on every execute"""
+    for shape, prec, r2c in (((8, 8, 10007), api.F64, 0), ((4, 20011, 4), api.F32, 0), ((8, 8, 6000), api.F64, 1)):
         with pytest.raises(RuntimeError, match="offt_3d_init failed"):
-            api.offt_3d_init(*shape, precision=prec)
+            api.offt_3d_init(*shape, precision=prec, is_r2c=r2c)
     po = api.offt_3d_init(8, 8, 5000)   # 5000 = 2^3 5^4 fits the any-length kernel
     api.offt_3d_fin(po)
 
