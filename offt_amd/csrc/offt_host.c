@@ -448,6 +448,7 @@ typedef struct hip_state {
   int pass_slot[3];
   int warned_in;
   struct step_list *rec; /* non-NULL: the schedule is being recorded, not run (multi-rank inverse) */
+  int rec_tag;           /* ... tag of the steps being recorded (see step) */
 } hip_state;
 
 /* ---- default backend: HIP + RCCL ----------------------------------------- */
@@ -1867,6 +1868,7 @@ typedef struct step {
   int first;              /* pass reads the caller's input layout (K1): it writes the inverse's result */
   offt_pass_desc d; const void *src; void *dst;
   int which, cnt; int *peer; const void **sp; size_t *sb; void **rp; size_t *rb;
+  int tag;                /* slab schedule: the z-chunk the step belongs to (-1: the K1 phase) */
 } step;
 typedef struct step_list { step *v; int n, cap; } step_list;
 
@@ -1886,7 +1888,7 @@ static int run_pass(hip_state *st, const offt_pass_desc *d, const void *src, voi
   if (st->skip_mask & 1) return 0; /* diagnostics: exchange-only timing */
   if (!st->rec) return st->be->pass(d, src, dst, stream);
   step *e = rec_new(st->rec);
-  e->kind = 0; e->first = first; e->d = *d; e->src = src; e->dst = dst;
+  e->kind = 0; e->first = first; e->d = *d; e->src = src; e->dst = dst; e->tag = st->rec_tag;
   return 0;
 }
 static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const void *const *sp, const size_t *sb,
@@ -1894,7 +1896,7 @@ static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const voi
   if (st->skip_mask & 2) return 0; /* diagnostics: compute-only timing */
   if (!st->rec) return st->be->a2a(st, which, cnt, peer, sp, sb, rp, rb, stream);
   step *e = rec_new(st->rec);
-  e->kind = 1; e->which = which; e->cnt = cnt;
+  e->kind = 1; e->which = which; e->cnt = cnt; e->tag = st->rec_tag;
   e->peer = (int *)malloc(sizeof(int) * cnt); e->sp = (const void **)malloc(sizeof(void *) * cnt);
   e->rp = (void **)malloc(sizeof(void *) * cnt); e->sb = (size_t *)malloc(sizeof(size_t) * cnt); e->rb = (size_t *)malloc(sizeof(size_t) * cnt);
   memcpy(e->peer, peer, sizeof(int) * cnt); memcpy(e->sp, sp, sizeof(void *) * cnt); memcpy(e->rp, rp, sizeof(void *) * cnt);
@@ -1936,8 +1938,27 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   int rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, -1);
   st->rec = NULL;
   be->event_record(st->evp[0], s);
-  for (int i = L.n - 1; i >= 0 && !rc; i--) {
+  /* Slab schedule over the staged exchange: the mirror image keeps the forward's overlap.  Chunk by chunk, last chunk first:
+   * FFTx^-1 and FFTy^-1 of chunk h on the compute stream, then the chunk's exchange (send and receive sides swapped) on the
+   * comm stream while the next chunk's passes run; the FFTz^-1 launches wait for the last exchange -- what the forward
+   * transform exposes at its start (K1) the inverse exposes at its end.  Every other schedule replays in order on one stream. */
+  const int overlap = st->slab_zyx && st->x1 && !st->p2p && st->sH > 0 && st->ev_sa && st->ev_s1 && st->sNt > 0;
+  for (int pass = 0; pass < (overlap ? st->sH + 1 : 1) && !rc; pass++) {
+   const int want_tag = overlap ? (pass < st->sH ? st->sH - 1 - pass : -1) : 0; /* chunks H-1 .. 0, then the K1 phase */
+   int chunk_exchanged = 0;
+   if (overlap && want_tag < 0) be->stream_wait(s, st->ev_s1[0]); /* every exchange has landed */
+   for (int kind_turn = 0; kind_turn < (overlap ? 2 : 1) && !rc; kind_turn++) /* a chunk's passes first, then its exchanges */
+   for (int i = L.n - 1; i >= 0 && !rc; i--) {
     step *e = &L.v[i];
+    void *sx = s;
+    if (overlap) {
+      if (e->tag != want_tag) continue;
+      if ((e->kind == 1) != (kind_turn == 1)) continue;
+      if (e->kind == 1) {
+        sx = st->s_comm1;
+        if (!chunk_exchanged) { be->event_record(st->ev_sa[want_tag], s); be->stream_wait(sx, st->ev_sa[want_tag]); chunk_exchanged = 1; }
+      }
+    }
     if (e->kind == 0) {
       offt_pass_desc d = e->d, f = e->d;
       d.direction = +1;
@@ -1948,14 +1969,16 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
       d.in_block_tab = f.out_block_tab; d.out_block_tab = f.in_block_tab;
       d.in_contig = f.out_contig; d.out_contig = f.in_contig;
       d.scale = e->first ? st->out_scale : 1.0;
-      rc = be->pass(&d, e->dst, (void *)e->src, s);
+      rc = be->pass(&d, e->dst, (void *)e->src, sx);
     } else if (e->kind == 2) {
       /* one barrier per recorded flag operation, never merged: ranks with an empty tile record no pass between two
        * operations where the others do, and every rank must run the same number of barriers */
-      rc = p2p_barrier(st, e->which, s);
+      rc = p2p_barrier(st, e->which, sx);
     } else {
-      rc = be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, s);
+      rc = be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, sx);
     }
+   }
+   if (overlap && chunk_exchanged) be->event_record(st->ev_s1[0], st->s_comm1); /* (in order on the comm stream: the last record covers all) */
   }
   be->event_record(st->evp[1], s);
   be->event_record(st->evp[2], s);
@@ -2126,6 +2149,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     if (run_signal(st, &st->g1, 0, ep, s) || run_wait(st, &st->g1, 0, ep, s)) return -1;
   } else if (st->x1) {
     for (int h = 0; h < H; h++) {
+      st->rec_tag = h;
       const int z0 = h * Tz;
       int tz = c->M3 - z0; if (tz > Tz) tz = Tz;
       /* y-contiguous layout: the volume is [peer][chunk][tile], so chunk h > 0 is ONE contiguous message per peer (RCCL runs
@@ -2157,6 +2181,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
   }
 
   for (int h = 0; h < H; h++) {
+    st->rec_tag = h;
     const int z0 = h * Tz;
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
@@ -2197,6 +2222,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       if (run_pass(st, &d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
     }
   }
+  st->rec_tag = -1;
   if (p2p && run_signal(st, &st->g1, 1, ep, s)) return -1; /* R1 is consumed: the peers may store the next transform */
   be->event_record(st->evp[2], s);
   be->event_record(st->evp[3], s);

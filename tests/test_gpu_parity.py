@@ -587,6 +587,6 @@ def test_harness_and_static_sweep(built, tmp_path):
                                     "-L", "64", "-v"], stderr=subprocess.STDOUT, timeout=300).decode()
     assert any(l.startswith("p 0: 0 0 0: ") for l in out3.splitlines()), out3
     # a run the library cannot do must FAIL: non-zero exit and the reference's t_min 999999999 line, not timings of
-    # an untransformed buffer (16384 points: no kernel takes the line)
-    p = subprocess.run([exe, "-N", "16384", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # an untransformed buffer (10007 points, a prime: no kernel takes the line and there is no n1 n2 to decompose along)
+    p = subprocess.run([exe, "-N", "10007", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode != 0 and "t_min 999999999" in p.stdout.decode(), p.stdout.decode()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layout", default="zyx")
     ap.add_argument("--t1", type=int, default=-1, help="x-tile thickness (default: the library's)")
     ap.add_argument("--t2", type=int, default=-1, help="z-chunk thickness (default: the library's)")
+    ap.add_argument("--inverse", type=int, default=0, help="1: time offt_3d_execute_dir(+1) (the mirrored schedule) instead of the forward transform")
     ap.add_argument("--touch", type=int, default=0, help="1: the first transform really fills the receive volumes (see the transport below)")
     ap.add_argument("--variants", default="", help="kernel variants vx,vy,vz (offt_hip_set_variant; 200 + id = column-pair variant id)")
     args = ap.parse_args()
@@ -76,7 +77,10 @@ def main():
         api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())  # every receive block written once
         state["touch"] = False
     for _ in range(args.reps):
-        api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+        if args.inverse:
+            api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+        else:
+            api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
         t = (C.c_double * 3)()
         L.offt_hip_last_pass_seconds(po, t)
         tot = L.offt_hip_last_device_seconds(po)
@@ -84,7 +88,7 @@ def main():
             best = (tot, list(t))
     local = float(n) ** 3 / args.ranks
     v = list(po.contents.params.contents.v)
-    print(f"rehearsal {n}^3 {args.dtype} rank 0 of {args.ranks}, mesh {c['p1']}x{c['p2']}, variants {args.variants or 'default'}, T1 {v[1]} W1 {v[2]} T2 {v[12]}: kernels only "
+    print(f"rehearsal {'INVERSE ' if args.inverse else ''}{n}^3 {args.dtype} rank 0 of {args.ranks}, mesh {c['p1']}x{c['p2']}, variants {args.variants or 'default'}, T1 {v[1]} W1 {v[2]} T2 {v[12]}: kernels only "
           f"{best[0]*1e3:.3f} ms per transform = {6*esz*local/best[0]/8e12*100:.1f} % of 8 TB/s on the rank's 6*S*E/P bytes "
           f"(phase 1 {best[1][0]*1e3:.3f} ms, last phase {best[1][2]*1e3:.3f} ms)", flush=True)
     api.offt_3d_fin(po)
