@@ -1969,6 +1969,9 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
       d.in_block_tab = f.out_block_tab; d.out_block_tab = f.in_block_tab;
       d.in_contig = f.out_contig; d.out_contig = f.in_contig;
       d.scale = e->first ? st->out_scale : 1.0;
+      /* cache hint: forward, a pass with out_keep is followed by the pass that re-reads its output; mirrored, that
+       * follower is the producer and this one the consumer */
+      d.out_keep = (i > 0 && L.v[i - 1].kind == 0 && L.v[i - 1].d.out_keep && !f.out_keep) ? 1 : 0;
       rc = be->pass(&d, e->dst, (void *)e->src, sx);
     } else if (e->kind == 2) {
       /* one barrier per recorded flag operation, never merged: ranks with an empty tile record no pass between two

@@ -9,7 +9,7 @@ rows = []
 for fn in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         if "fft_" in r["Kernel_Name"]:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", r.get("Queue_Id", "?")), r["Grid_Size"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", r.get("Queue_Id", "?")), r.get("Grid_Size", r.get("Grid_Size_X", "?"))))
 rows.sort()
 rows = rows[-28:]
 t0 = rows[0][0]
