@@ -1076,7 +1076,9 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   st->opt.comm_streams = getenv("OFFT_COMM_STREAMS") ? atoi(getenv("OFFT_COMM_STREAMS")) : 1;
   st->opt.min_msg = getenv("OFFT_MIN_MSG") ? atoll(getenv("OFFT_MIN_MSG")) : 4LL << 20;
   st->opt.f32_pairs = !(getenv("OFFT_F32_PAIRS") && atoi(getenv("OFFT_F32_PAIRS")) == 0);
-  st->opt.block_pad = !(getenv("OFFT_BLOCK_PAD") && atoi(getenv("OFFT_BLOCK_PAD")) == 0);
+  /* (off by default: measured, it buys nothing -- the power-of-two block pitches are NOT what holds K1 / K2 back,
+   * profiles/r03_rehearse_block_pad_ab.txt; OFFT_BLOCK_PAD=1 turns it on) */
+  st->opt.block_pad = getenv("OFFT_BLOCK_PAD") && atoi(getenv("OFFT_BLOCK_PAD")) != 0;
   st->opt.exec_timeout_s = getenv("OFFT_EXEC_TIMEOUT") ? atof(getenv("OFFT_EXEC_TIMEOUT")) : 120.0;
   st->opt.p2p_timeout_s = getenv("OFFT_P2P_TIMEOUT") ? atof(getenv("OFFT_P2P_TIMEOUT")) : 30.0;
   st->want_p2p = getenv("OFFT_EXCHANGE") && !strcmp(getenv("OFFT_EXCHANGE"), "p2p");
@@ -1767,7 +1769,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
    * the two ALTERNATE over groups of z-planes small enough for the 256 MiB memory-side Infinity Cache: y(group) stores
    * with the default cache policy (out_keep), x(group) finds its input there instead of in HBM -- one of the six
    * read/write sweeps of the transform is served by the cache.  1024^3 f64: y + x 11.5 -> 10.7 ms, the transform
-   * 17.3 -> 16.5 ms (tools/dev_mall_probe.py, profiles/r02_mall_probe.txt, r02_zgroup*.txt).  OFFT_ZGROUP_MIB sets
+   * 17.3 -> 16.5 ms (tools/mall_probe.py, profiles/r02_mall_probe.txt, r02_zgroup*.txt).  OFFT_ZGROUP_MIB sets
    * the group size (0: off). */
   st->yx_fused = 0;
   /* (lines of up to 1024 points: the 2048-point kernels fill a CU with one workgroup, a group launch of theirs ends in
@@ -2059,9 +2061,10 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   st->sblkS = (size_t)c->M3 * c->M2 * T;
   /* y-contiguous block layout (see execute_slab): needs even z blocks that are whole chunks */
   st->slab_yc = c->b3 == 0 && c->M3 % Tz == 0 && !(getenv("OFFT_SLAB_XC_LAYOUT") && atoi(getenv("OFFT_SLAB_XC_LAYOUT")));
-  /* y-contiguous layout: a (peer, chunk) block holds its nt tiles, then a pad of nine 128-B lines.  Without it the p2 * H
-   * blocks one K1 workgroup stores into (and the p2 blocks a K2 line is read from) sit a power of two apart -- 32 MiB at
-   * 1024^3 on 8 ranks -- and fall on the same HBM channels, like the x-planes of the single-rank scratch volume (wpad) */
+  /* y-contiguous layout: a (peer, chunk) block holds its nt tiles, then -- optionally -- a pad of nine 128-B lines, so that
+   * the p2 * H blocks one K1 workgroup stores into (and the p2 blocks a K2 line is read from) do not sit a power of two
+   * apart (32 MiB at 1024^3 on 8 ranks).  For the x-planes of the single-rank scratch volume such a pad pays (wpad); here
+   * it measured as nothing, so it is off by default (opt.block_pad) */
   st->sBc = (size_t)c->M2 * Tz * T * st->sNt + (st->opt.block_pad ? 1152 / st->esz : 0);
   const size_t vol = (st->slab_yc ? st->sBc * st->sH : st->sblkS * st->sNt) * c->p2;
   /* (direct-store exchange: no send volume -- K1 stores into the peers' R1, its own block into its own) */

@@ -340,7 +340,7 @@ fill_real_k(T *buf, int kind, int n0, int n1, int n2, int s0, int s1, int s2, lo
 std::once_flag g_reg_once;
 void build_registry() {
   registry().reserve(8192);  // plan-time instances are appended later: no reallocation under a concurrent lookup
-#ifdef OFFT_DEV_REGISTRY  /* developer switch: only the kernels of offt_reg_dev.hip, for quick iteration */
+#ifdef OFFT_DEV_REGISTRY  /* the static-sweep tool (tools/sweep_mixed.py) builds the library with ONLY its candidate kernels, in a reg_dev.hip it generates */
   reg_dev();
 #else
   reg_pow2_f64();
@@ -395,7 +395,7 @@ Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = f
 // Plan-time specialisation.  A length without a precompiled panel kernel whose prime factors are <= 31 gets
 // its own fft_panelx_k instances at offt_hipk_prepare(): the device part of offt_panel.hpp travels inside
 // the library as a string, a shape (radix order, threads per line, panel width) is picked with the scoring of
-// tools/dev_sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours and the two real-input ones (2-4 s in all) and the
+// tools/sweep_mixed.py, hipRTC compiles the four (in_contig, out_contig) flavours and the two real-input ones (2-4 s in all) and the
 // code object is loaded as a module.  OFFT_RTC=0 turns it off; any failure leaves the any-length kernel in
 // charge and says why on stderr once.
 // ---------------------------------------------------------------------------
@@ -453,7 +453,7 @@ bool smooth13(int n) {
 }
 int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 
-// the candidate scoring of tools/dev_sweep_mixed.py (live butterfly slots, waves per CU, panel width, radix size)
+// the candidate scoring of tools/sweep_mixed.py (live butterfly slots, waves per CU, panel width, radix size)
 bool choose_shapes(int N, int prec, int want, std::vector<Shape> *out) {
   const int esz = prec == OFFT_PREC_F64 ? 8 : 4, emax_cap = 32, emax_soft = prec == OFFT_PREC_F64 ? 24 : 32;
   std::vector<int> rad;

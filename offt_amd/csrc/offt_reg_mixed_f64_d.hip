@@ -1,6 +1,6 @@
 // offt_reg_mixed_f64_d.hip -- double-precision mixed-radix (2^a 3^b 5^c) panel kernels, group d of 4.
 // One shape per length: <T, N, threads per line, R0, R1, R2, columns, split re/im exchange>, the winner of the
-// static sweep over radix order x threads per line x panel width (tools/dev_sweep_mixed.py, every candidate and
+// static sweep over radix order x threads per line x panel width (tools/sweep_mixed.py, every candidate and
 // its time in profiles/r01_mixed_sweep_f64.txt).  The percentage is algorithmic bytes / time of the passes of that
 // length against 8 TB/s, measured on an N^3 grid (an N x 256 x N slab above 1600).
 #include "offt_panel.hpp"

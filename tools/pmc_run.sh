@@ -2,7 +2,7 @@
 # Run on the GPU box: hardware counters per kernel of one tool run, three separate --pmc passes (8 SQ slots / 4 TCC slots
 # per pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"), never combined with a trace.  The program goes directly after `--`.
 #   tools/pmc_run.sh <tag> tools/rehearse_rank.py --n 1024 --ranks 8 --p1 1
-#   tools/pmc_run.sh <tag> tools/dev_shape.py 2048,256,2048 f32 0 2
+#   tools/pmc_run.sh <tag> tools/shape_probe.py 2048,256,2048 f32 0 2
 # summary -> gpurun_out/pmc_<tag>.txt (copy into profiles/ to keep it)
 export TMPDIR=/tmp
 TAG=$1; shift
