@@ -16,7 +16,7 @@ $(BUILD):
 	mkdir -p $(BUILD)
 
 # the kernel instantiations are grouped into several translation units so that `make -j` compiles them in parallel
-HIPSRC    := offt_reg_pow2_f32_big offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f64_1024 offt_reg_pow2_f64_anysplit offt_reg_pow2_f32 offt_reg_pow2_f32_anysplit offt_reg_pow2_f32_pair offt_reg_mixed_f64_a offt_reg_mixed_f64_b \
+HIPSRC    := offt_reg_pow2_f32_big offt_kernels offt_reg_pow2_f64 offt_reg_pow2_f64_1024 offt_reg_pow2_f64_anysplit offt_reg_pow2_f32 offt_reg_pow2_f32_anysplit offt_reg_pow2_f32_pair offt_reg_pow2_tw4 offt_reg_mixed_f64_a offt_reg_mixed_f64_b \
              offt_reg_mixed_f64_c offt_reg_mixed_f64_d offt_reg_mixed_f64_e offt_reg_mixed_f32_a offt_reg_mixed_f32_b offt_reg_bluestein offt_reg_bluestein_f32
 HIPOBJ    := $(HIPSRC:%=$(BUILD)/%.o)
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/offt_panel.hpp $(CSRC)/offt_bluestein.hpp $(CSRC)/offt_hipk.h $(CSRC)/offt_w32_consts.h $(CSRC)/offt_wr_consts.h | $(BUILD)

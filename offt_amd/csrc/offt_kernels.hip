@@ -350,6 +350,7 @@ void build_registry() {
   reg_pow2_f32_big();
   reg_pow2_f32_anysplit();
   reg_pow2_f32_pair();
+  reg_pow2_tw4();
   reg_mixed_f64_a();
   reg_mixed_f64_b();
   reg_mixed_f64_c();
@@ -366,21 +367,21 @@ void build_registry() {
 std::mutex g_idx_mu;
 std::unordered_map<unsigned long long, std::vector<int>> g_idx;
 size_t g_idx_size = 0;
-unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c, bool keep = false) {
-  return ((unsigned long long)n << 8) | (keep ? 32u : 0u) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
+unsigned long long variant_key(int n, int prec, bool inc, bool outc, bool r2c, bool keep = false, bool tw4 = false) {
+  return ((unsigned long long)n << 8) | (tw4 ? 64u : 0u) | (keep ? 32u : 0u) | ((unsigned long long)prec << 3) | (inc ? 4u : 0u) | (outc ? 2u : 0u) | (r2c ? 1u : 0u);
 }
 
-Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false, bool keep = false) {
+Variant *find_variant(int n, int prec, bool inc, bool outc, int id, bool r2c = false, bool keep = false, bool tw4 = false) {
   std::call_once(g_reg_once, build_registry);
   std::lock_guard<std::mutex> lk(g_idx_mu);
   auto &reg = registry();
   if (g_idx_size != reg.size()) {
     g_idx.clear();
     for (size_t i = 0; i < reg.size(); ++i)
-      g_idx[variant_key(reg[i].n, reg[i].prec, reg[i].inc, reg[i].outc, reg[i].r2c, reg[i].keep)].push_back((int)i);
+      g_idx[variant_key(reg[i].n, reg[i].prec, reg[i].inc, reg[i].outc, reg[i].r2c, reg[i].keep, reg[i].tw4)].push_back((int)i);
     g_idx_size = reg.size();
   }
-  auto it = g_idx.find(variant_key(n, prec, inc, outc, r2c, keep));
+  auto it = g_idx.find(variant_key(n, prec, inc, outc, r2c, keep, tw4));
   if (it == g_idx.end()) return nullptr;
   Variant *def = nullptr;
   for (int i : it->second) {
@@ -787,6 +788,11 @@ Variant *pick_variant0(const offt_pass_desc *d, bool allow_pair) {
 
 // ... and its cache-keeping twin when the descriptor asks for one (out_keep) and one is registered
 Variant *pick_variant(const offt_pass_desc *d, bool allow_pair = true) {
+  if (d->tw4) {  // first sub-pass of a four-step line: the strided / strided kernel with the twiddles on its stores, or nothing
+    if (d->in_contig || d->out_contig || d->real_input || d->in_split_nfloor || d->out_split_nfloor) return nullptr;
+    if ((d->in_split && !is_pow2(d->in_split)) || (d->out_split && !is_pow2(d->out_split))) return nullptr;
+    return find_variant(d->n, d->precision, false, false, -1, false, false, true);
+  }
   Variant *v = pick_variant0(d, allow_pair);
   static const bool keep_on = !(getenv("OFFT_KEEP_STORES") && atoi(getenv("OFFT_KEEP_STORES")) == 0);
   if (v && d->out_keep && keep_on && !v->mixed && !v->r2c) {
@@ -1050,6 +1056,8 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.scale = d->scale;
     a.in_tab = d->in_split ? d->in_block_tab : nullptr;
     a.out_tab = d->out_split ? d->out_block_tab : nullptr;
+    a.tw4 = d->tw4; a.tw4_b1 = d->tw4_b1;
+    if (d->tw4 && !(v && v->tw4)) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: no kernel with four-step twiddles for n=%d", d->n); return -1; }
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
     xcd_order(nblk, &a.xcd_lim, &a.xcd_gshift);
@@ -1192,6 +1200,13 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
         a.in_axis_stride = (long long)N2 * d->in_axis_stride;
         if (d->in_split) { a.in_split = d->in_split / N2; a.in_block_stride = d->in_block_stride; a.in_block_tab = d->in_block_tab; }
         a.in_contig = 0; a.out_contig = 0;
+        // twiddles fused into A's stores when the n1-point kernel has such a twin: two sweeps instead of three.  A strided-in
+        // pass then leaves S'[k1][j2][c] as it is and C reads it with the caller's columns as its columns -- which needs a
+        // strided-out pass as well; strided-in / contig-out keeps the transposing twiddle sweep.
+        static const bool fuse_on = !(getenv("OFFT_FOURSTEP_FUSE") && atoi(getenv("OFFT_FOURSTEP_FUSE")) == 0);
+        const bool fused = fuse_on && (inL || !outL) && (!d->in_split || is_pow2(d->in_split / N2)) &&
+                           find_variant(N1, d->precision, false, false, -1, false, false, true) != nullptr;
+        if (fused) { a.tw4 = tb.full; a.tw4_b1 = inL ? 0 : 1; }
         if (inL) {  // the axis is the unit-stride dimension: j2 becomes the column dimension
           a.ncols = N2; a.in_col_stride = d->in_axis_stride;
           a.nb1 = nc; a.in_b1_stride = d->in_col_stride;
@@ -1203,12 +1218,14 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
           a.nb1 = N2; a.in_b1_stride = d->in_axis_stride;
           a.nb2 = nb; a.in_b2_stride = d->in_b1_stride;
           a.out_axis_stride = (long long)N2 * nc; a.out_col_stride = 1; a.out_b1_stride = nc; a.out_b2_stride = (long long)N * nc;
-          if (offt_hipk_fft_pass(&a, pin, Sp, stream)) return -1;
+          if (offt_hipk_fft_pass(&a, pin, fused ? S : Sp, stream)) return -1;
         }
         // ---- T: twiddles w_n^(j2 k1) (and the transposition S' -> S) ----
         (void)hipGetLastError();
         const int conj = d->direction > 0;
-        if (inL) {
+        if (fused) {
+          /* nothing: the twiddles rode on A's stores */
+        } else if (inL) {
           const long long total = (long long)nc * nb * N;
           const unsigned blocks = (unsigned)((total + 255) / 256);
           if (d->precision == OFFT_PREC_F64)
@@ -1231,7 +1248,12 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
         c.in_axis_stride = 1; c.in_contig = 1; c.out_contig = 0;
         c.out_axis_stride = (long long)N1 * d->out_axis_stride;
         if (d->out_split) { c.out_split = d->out_split / N1; c.out_block_stride = d->out_block_stride; c.out_block_tab = d->out_block_tab; }
-        if (outL) {  // k1 becomes the column dimension of the output
+        if (fused && !inL) {  // S'[b][k1][j2][c] straight from A: the caller's columns are the columns on both sides
+          c.in_contig = 0; c.in_axis_stride = nc;
+          c.ncols = nc; c.in_col_stride = 1; c.out_col_stride = d->out_col_stride;
+          c.nb1 = N1; c.in_b1_stride = (long long)N2 * nc; c.out_b1_stride = d->out_axis_stride;
+          c.nb2 = nb; c.in_b2_stride = (long long)N * nc; c.out_b2_stride = d->out_b1_stride;
+        } else if (outL) {  // k1 becomes the column dimension of the output
           c.ncols = N1; c.in_col_stride = N2; c.out_col_stride = d->out_axis_stride;
           c.nb1 = nc; c.in_b1_stride = N; c.out_b1_stride = d->out_col_stride;
           c.nb2 = nb; c.in_b2_stride = (long long)N * nc; c.out_b2_stride = d->out_b1_stride;

@@ -196,6 +196,8 @@ struct PassArgs {
   unsigned xcd_gshift;      // log2 G, G = run of neighbouring panels one XCD takes
   double scale;
   const long long *in_tab, *out_tab;  // per-block element offsets (offt_pass_desc::in_block_tab / out_block_tab) or nullptr
+  const void *tw4;          // TW4 kernels (first sub-pass of a four-step line): the exact full-wave table of the LONG length;
+  int tw4_b1;               //   output index k1 of column j2 (tw4_b1 = 0) or of batch entry j2 = b1 (tw4_b1 = 1) times w^(k1 j2)
 };
 
 template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
@@ -262,7 +264,8 @@ __device__ __forceinline__ int padidx(int i) {
 }
 
 template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool INC, bool OUTC, bool SPLIT, bool R2C = false,
-          bool KEEP = false /* stores with the default cache policy: the next launch re-reads the output (out_keep) */>
+          bool KEEP = false /* stores with the default cache policy: the next launch re-reads the output (out_keep) */,
+          bool TW4 = false /* four-step lines (offt_kernels.hip): the twiddles w_n^(j2 k1) of the long length ride on the stores */>
 __global__ void __launch_bounds__((N / E) * COLS, (PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>::WPS_E))
 fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *out,
             const typename vec2<T>::type *twq) {
@@ -279,6 +282,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
   static_assert(R0 * R1 * R2 == N, "radices must multiply to N");
   static_assert(E % R0 == 0 && E % R1 == 0 && E % R2 == 0 && N % E == 0, "bad E");
   static_assert(!(PAIR && R2C), "column pairs: complex input only");
+  static_assert(!(PAIR && TW4), "four-step twiddles: one column per lane");
 
   extern __shared__ __align__(16) unsigned char smem[];
   T *exs = reinterpret_cast<T *>(smem);
@@ -510,6 +514,12 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
           constexpr int cn = u * TPL + t * (N / R);
           const int n = j + cn;
           cx<T> x = v[u * R + bitrev(t, LR)];
+          if constexpr (TW4) {
+            // times w^(k1 j2) of the long line, before the conj-out / scale below (for the inverse conj(v w) = conj(v) conj(w))
+            const long long jj = a.tw4_b1 ? b1 : (c0 + c);
+            const V2 w = reinterpret_cast<const V2 *>(a.tw4)[(long long)n * jj];
+            x = cx<T>{x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
+          }
           long long off = (long long)(cn & mask) * a.out_axis;  // uniform
           if constexpr (TAB) off += a.out_tab[jb + (cn >> a.out_shift)];
           else off += (long long)(cn >> a.out_shift) * a.out_blk;  // uniform
@@ -897,6 +907,7 @@ struct Variant {
   bool full_table;
   void *modfn;      // hipFunction_t of an instance compiled at plan time (hipRTC), launched instead of fn
   bool keep = false;  // KEEP instantiation (offt_pass_desc::out_keep): default-policy stores
+  bool tw4 = false;   // TW4 instantiation (offt_pass_desc::tw4): four-step twiddles on the stores
 };
 // id of the fft_panelx_k instance a power-of-two length keeps for per-peer splits fft_panel_k cannot address
 // (uneven, or not a power of two: grids split over 3, 6, ... ranks)
@@ -935,6 +946,19 @@ void reg_variant(int id, int defmask = -1) {
     add(true, true, F_CC, (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, true, true, SPLIT, false, true>);
     registry().back().keep = true;
   }
+}
+
+// strided / strided instance with the four-step twiddles on its stores (the first sub-pass of a long line, offt_kernels.hip)
+template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
+void reg_variant_tw4(int id) {
+  using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
+  const int prec = std::is_same<T, double>::value ? OFFT_PREC_F64 : OFFT_PREC_F32;
+  char nm[160];
+  snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d four-step twiddles on the stores lds=%zuB", prec ? "f32" : "f64", N, E, R0, R1, R2,
+           COLS, (size_t)Cfg::LDS_BYTES);
+  registry().push_back(Variant{N, prec, false, false, id, true, false, COLS, Cfg::NT, E, Cfg::LDS_BYTES,
+                               (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT, false, false, true>, nm, false, false, false, nullptr});
+  registry().back().tw4 = true;
 }
 
 // column-pair instances of fft_panel_k (T = f32x2): kept under their own precision key so that the one-column variants and
@@ -999,6 +1023,7 @@ void reg_pow2_f32();
 void reg_pow2_f32_big();
 void reg_pow2_f32_anysplit();
 void reg_pow2_f32_pair();
+void reg_pow2_tw4();
 void reg_mixed_f64_a();
 void reg_mixed_f64_b();
 void reg_mixed_f64_c();
