@@ -85,5 +85,5 @@ asan-test: $(HIPOBJ)
 	cp tests/libcpubackend.so $(BUILD)/asan/libcpubackend.so.orig
 	cp $(BUILD)/asan/libcpubackend.so tests/libcpubackend.so
 	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-	  OFFT_AMD_TEST_LIB=$(CURDIR)/$(BUILD)/asan/liboffthip.so python -m pytest tests/test_host_logic.py -x -q; \
+	  OFFT_AMD_TEST_LIB=$(CURDIR)/$(BUILD)/asan/liboffthip.so python -m pytest tests/test_host_logic.py tests/test_p2p_world.py -x -q; \
 	  rc=$$?; cp $(BUILD)/asan/libcpubackend.so.orig tests/libcpubackend.so; exit $$rc

@@ -119,6 +119,39 @@ def test_single_rank_forced_pipeline(cpu1, monkeypatch):
         assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, (shape, kw)
 
 
+def test_plan_options_and_exchange_setter(cpu1, monkeypatch):
+    """offt_hip_set_option / offt_hip_get_option / offt_hip_set_exchange (include/offt_hip.h): options are plan state, read
+    from the environment only at offt_3d_init; the ones that shape buffers rebuild them; the transform stays right"""
+    monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
+    monkeypatch.setenv("OFFT_ZGROUP_MIB", "7")
+    L = api.lib()
+    shape = (12, 6, 10)
+    po = api.offt_3d_init(*shape, custom_params=api.make_params(T1=5, T2=3))
+    OPT = dict(ZGROUP_MIB=0, ZGROUP_STREAMS=1, SLAB_CHUNK_MIB=2, COMM_STREAMS=3, F32_PAIRS=4, K1_STREAMS=5, SELF_BYPASS=6, MIN_MSG=7,
+               EXEC_TIMEOUT_S=8, P2P_TIMEOUT_S=9)
+    assert L.offt_hip_get_option(po, OPT["ZGROUP_MIB"]) == 7          # the environment's value became the plan's default ...
+    monkeypatch.setenv("OFFT_ZGROUP_MIB", "99")
+    assert L.offt_hip_get_option(po, OPT["ZGROUP_MIB"]) == 7          # ... and later changes of the environment do not reach the plan
+    for name, val in (("ZGROUP_MIB", 3), ("ZGROUP_STREAMS", 2), ("SLAB_CHUNK_MIB", 1), ("COMM_STREAMS", 2), ("F32_PAIRS", 0), ("K1_STREAMS", 2),
+                      ("SELF_BYPASS", 0), ("MIN_MSG", 0), ("EXEC_TIMEOUT_S", 17), ("P2P_TIMEOUT_S", 5)):
+        assert L.offt_hip_set_option(po, OPT[name], val) == 0, name
+        assert L.offt_hip_get_option(po, OPT[name]) == val, name
+    assert L.offt_hip_set_option(po, 12345, 1) != 0                   # unknown option
+    assert L.offt_hip_get_exchange(po) == 0
+    assert L.offt_hip_set_exchange(po, 1) == 0                        # a world of one: nothing to map, the staged exchange stays
+    c = api.comm_dict(po)
+    buf = np.zeros(api.local_elems(po), dtype=np.complex128)
+    s0, s1, s2 = c["istride"]
+    idx = (np.arange(shape[0])[:, None, None] * s0 + np.arange(shape[1])[None, :, None] * s1 + np.arange(shape[2])[None, None, :] * s2).ravel()
+    buf[idx] = O.hash_field(*shape).ravel()
+    ptr = buf.ctypes.data_as(C.c_void_p)
+    api.offt_3d_execute(po, ptr, ptr)
+    G = np.zeros(shape, dtype=np.complex128)
+    cpu_world.scatter_out(c, buf, G)
+    api.offt_3d_fin(po)
+    assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
+
+
 def test_forced_self_exchange(cpu1, monkeypatch):
     """p = 1 with the exchanges forced on: separate send/receive buffers and the a2a callback in the loop"""
     monkeypatch.setenv("OFFT_FORCE_PIPELINE", "1")
