@@ -12,9 +12,9 @@ out, what = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
 
 
 def short(name):
-    m = re.search(r"(fft_panelx?_k)<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+), (\w+))?", name)
+    m = re.search(r"(fft_panelx?_k)<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+), (\w+))?(?:, (\w+))?", name)
     if m:
-        k, t, N, E, r0, r1, r2, cols, inc, outc, split, r2c, keep = m.groups()
+        k, t, N, E, r0, r1, r2, cols, inc, outc, split, r2c, keep, _tw4 = m.groups()
         t = {"HIP_vector_type<float, 2>": "f32x2"}.get(t, t)
         return (f"{k}<{t},N={N},{'E' if k == 'fft_panel_k' else 'TPL'}={E},{r0}x{r1}x{r2},cols={cols},"
                 f"{'C' if inc == 'true' else 'S'}{'C' if outc == 'true' else 'S'},{'split' if split == 'true' else 'packed'}"

@@ -22,9 +22,9 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"fft_panel_k<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
+    m = re.search(r"fft_panel_k<([\w ()]+?), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", name)
     if m:
-        t, N, E, r0, r1, r2, cols, inc, outc, split, r2c, keep = m.groups()
+        t, N, E, r0, r1, r2, cols, inc, outc, split, r2c, keep, _tw4 = m.groups()
         return (f"fft_panel_k<{t},N={N},E={E},radix={r0}x{r1}x{r2},cols={cols},in_contig={inc},out_contig={outc},"
                 f"split={split}{',real_in' if r2c == 'true' else ''}{',keep' if keep in ('true', '1') else ''}>")
     return re.sub(r"\(.*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))[:100]
