@@ -2225,6 +2225,8 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       d.in_axis_stride = 1; d.in_col_stride = c->M1; d.in_b1_stride = (long long)c->M4 * c->M1; d.in_contig = 1;
       d.out_axis_stride = c->ostride[0]; d.out_col_stride = c->ostride[1]; d.out_b1_stride = c->ostride[2]; d.out_contig = 1;
       d.scale = st->out_scale;
+      /* (K3(h) on a second stream, so that K2(h + 1) shares the chip with it, was tried: 1.439 against 1.443 ms for the
+       *  chunked phase at 1024^3 on 8 ranks -- nothing; profiles/r03_rehearse_k3_stream.txt) */
       if (run_pass(st, &d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
     }
   }

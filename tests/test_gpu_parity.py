@@ -350,9 +350,54 @@ def test_full_size_2048_single_precision_properties(built):
     L.offt_hip_set_output_scale(po, 2.0 ** -16)   # exact power of two: |X|^2 scaled by 2^-32 = 1 / sqrt(E)^... see below
     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
     e_out = energy()
-    api.offt_3d_fin(po)
     # E = 2^33, scale^2 = 2^-32: e_out = 2^-32 * 2^33 * e_in = 2 e_in
     assert abs(e_out / (2.0 * e_in) - 1.0) < 1e-5
+    # FULL-GRID rel-L2 at this size: forward, then the inverse, against the input (scales 2^-16 and 2^-17: together 1 / E,
+    # exact powers of two) -- every element of the 2^33-point grid takes part, chunked reductions in float64
+    torch.cuda.synchronize()
+    L.offt_hip_fill_input(po, dev.data_ptr(), 1)
+    torch.cuda.synchronize()
+    x0 = dev.clone()
+    torch.cuda.synchronize()
+    L.offt_hip_set_output_scale(po, 2.0 ** -16)
+    api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
+    L.offt_hip_set_output_scale(po, 2.0 ** -17)
+    api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+    num = den = 0.0
+    step = 1 << 28
+    for i in range(0, dev.numel(), step):
+        a, b = dev[i:i + step].double(), x0[i:i + step].double()
+        num += float((a - b).square().sum())
+        den += float(b.square().sum())
+    api.offt_3d_fin(po)
+    assert (num / den) ** 0.5 < TOL32, (num / den) ** 0.5
+
+
+def test_full_size_1024_single_precision_full_grid_vs_double(built):
+    """1024^3: the single-precision transform against the double-precision one of the same field, FULL grid, rel-L2 <= 5e-6
+    (the double-precision result at this size is itself checked by closed forms and Parseval above, and against the
+    oracle at the sizes the oracle finishes)"""
+    n = 1024
+    L = api.lib()
+    po64 = api.offt_3d_init(n, n, n)
+    d64 = torch.zeros(api.local_elems(po64) * 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    L.offt_hip_fill_input(po64, d64.data_ptr(), 1)
+    api.offt_3d_execute(po64, d64.data_ptr(), d64.data_ptr())
+    api.offt_3d_fin(po64)
+    po32 = api.offt_3d_init(n, n, n, precision=api.F32)
+    d32 = torch.zeros(api.local_elems(po32) * 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    L.offt_hip_fill_input(po32, d32.data_ptr(), 1)
+    api.offt_3d_execute(po32, d32.data_ptr(), d32.data_ptr())
+    api.offt_3d_fin(po32)
+    num = den = 0.0
+    step = 1 << 27
+    for i in range(0, d64.numel(), step):
+        a, b = d32[i:i + step].double(), d64[i:i + step]
+        num += float((a - b).square().sum())
+        den += float(b.square().sum())
+    assert (num / den) ** 0.5 < TOL32, (num / den) ** 0.5
 
 
 @pytest.mark.parametrize("shape,prec,kw", [((8, 8, 6000), api.F64, {}), ((16384, 4, 4), api.F64, {}), ((4, 12000, 4), api.F32, {}),
