@@ -1132,17 +1132,23 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
   if (!st->s_compute || !st->ev0 || !st->ev1) goto fail;
 
   if (!st->use_pipeline) {
+    /* layouts whose x pass would walk memory plane by plane (x-y-z; y-z-x) rotate through a second scratch volume instead
+     * when an x-plane is a whole number of MiB (see execute_single); OFFT_ROTATE=1 / 0 forces either (OFFT_S1_INPLACE=1 is
+     * the older name of OFFT_ROTATE=0) */
+    const char *renv = getenv("OFFT_ROTATE") ? getenv("OFFT_ROTATE") : (getenv("OFFT_S1_INPLACE") ? (atoi(getenv("OFFT_S1_INPLACE")) ? "0" : "1") : NULL);
+    const int rotate = renv ? atoi(renv) != 0 : ((size_t)Ny * (size_t)(is_r2c ? Nz / 2 + 1 : Nz) * st->esz) % ((size_t)1 << 20) == 0;
     if (!po->params->v[_S_]) { /* transposed output layouts need one scratch volume */
       st->work_elems = (size_t)Nx * ((size_t)(Ny + st->wrow) * (is_r2c ? Nz / 2 + 1 : Nz) + (size_t)st->wpad);
       st->work = be->dmalloc(st->work_elems * st->esz);
       if (!st->work) goto fail;
-    } else if (getenv("OFFT_S1_INPLACE") ? !atoi(getenv("OFFT_S1_INPLACE"))
-                                         : ((size_t)Ny * (size_t)(is_r2c ? Nz / 2 + 1 : Nz) * st->esz) % ((size_t)1 << 20) == 0) {
+      if (rotate && is_equalxy && po->comm->M1 == po->comm->M4) /* y-z-x: V[z][y][x]; without it the older schedule runs */
+        st->work2 = be->dmalloc((size_t)(is_r2c ? Nz / 2 + 1 : Nz) * ((size_t)Nx * Ny + (size_t)st->wpad) * st->esz);
+    } else if (rotate) {
       /* x-y-z output: two scratch volumes for the rotating schedule of execute_single, W[y][z][x] and V[z][x][y].  Used when
        * an x-plane is a whole number of MiB -- then the in-place x pass, whose lines step through memory plane by plane,
        * keeps hitting the same HBM channels (1024^3 f64: 7.8 ms = 55 % against 5.9 ms; 512^3: 0.95 against 0.72 ms), while
        * at other pitches (768^3: 9 MiB planes) the in-place passes are as fast and need no scratch
-       * (profiles/r03_layouts.txt).  OFFT_S1_INPLACE=1 / 0 forces either.  Without the volumes (allocation failed) the
+       * (profiles/r03_layouts.txt).  OFFT_ROTATE=0 / 1 forces either.  Without the volumes (allocation failed) the
        * three passes run in place. */
       const size_t nzc = (size_t)(is_r2c ? Nz / 2 + 1 : Nz);
       st->work = be->dmalloc((size_t)Ny * (nzc * Nx + (size_t)st->wpad) * st->esz);
@@ -1622,7 +1628,7 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   const int S = po->params->v[_S_] != 0;
   const int zyx = !S && !(po->is_equalxy && c->M1 == c->M4);
 
-  int s1_rot = 0;
+  int s1_rot = 0, yzx_rot = 0;
   if (S && st->work && st->work2) {
     /* x-y-z output == input layout, x outermost on both sides: an FFT along x that touched this layout directly would walk
      * memory at a plane-sized stride (16 MiB at 1024^3: 56 % of the roofline, profiles/r02_layouts_zgroup.txt).  Instead
@@ -1732,8 +1738,46 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
       src[0] = data; dst[0] = data; src[1] = data; dst[1] = W; src[2] = W; dst[2] = data;
       slot[0] = 2; slot[1] = 1; slot[2] = 0;
     }
+  } else if (st->work2) {
+    /* y-z-x output (is_equalxy) as a variation of the z-y-x schedule: the same two rotations, the second one into a second
+     * scratch volume V[z][y][x], and the x pass -- whole contiguous lines on both sides -- puts every line where the
+     * caller's layout wants it (line (y, z) at y * ostride[1] + z * ostride[2]):
+     *   P1  in[x][y][z] --FFTz--> W[x][z][y]     P2  W --FFTy--> V[z][y][x]     P3  V --FFTx--> out[y][z][x]
+     * (the older schedule below reads its x lines out of W[x][y][z] at a plane-sized stride: 62 % on that pass) */
+    const long long wy = Ny + st->wrow, wx = (long long)Nz * wy + st->wpad;
+    const long long vz = (long long)Nx * Ny + st->wpad;
+    void *V = st->work2;
+    yzx_rot = 1;
+    desc_init(&d[0], st, Nzf, dir, 2);
+    d[0].real_input = po->is_r2c;
+    desc_init(&d[1], st, Ny, dir, 1);
+    desc_init(&d[2], st, Nx, dir, 0);
+    d[0].ncols = Ny; d[0].nb1 = Nx;
+    d[1].ncols = Nx; d[1].nb1 = Nz;
+    d[2].ncols = Ny; d[2].nb1 = Nz;
+    if (dir < 0) {
+      d[0].in_axis_stride = 1; d[0].in_col_stride = is1; d[0].in_b1_stride = is0; d[0].in_contig = 1;
+      d[0].out_axis_stride = wy; d[0].out_col_stride = 1; d[0].out_b1_stride = wx; d[0].out_contig = 0;
+      d[1].in_axis_stride = 1; d[1].in_col_stride = wx; d[1].in_b1_stride = wy; d[1].in_contig = 1;
+      d[1].out_axis_stride = Nx; d[1].out_col_stride = 1; d[1].out_b1_stride = vz; d[1].out_contig = 0;
+      d[2].in_axis_stride = 1; d[2].in_col_stride = Nx; d[2].in_b1_stride = vz; d[2].in_contig = 1;
+      d[2].out_axis_stride = os0; d[2].out_col_stride = os1; d[2].out_b1_stride = os2; d[2].out_contig = 1;
+      src[0] = data; dst[0] = W; src[1] = W; dst[1] = V; src[2] = V; dst[2] = data;
+      slot[0] = 0; slot[1] = 1; slot[2] = 2;
+    } else {
+      offt_pass_desc t;
+      d[2].in_axis_stride = os0; d[2].in_col_stride = os1; d[2].in_b1_stride = os2; d[2].in_contig = 1;
+      d[2].out_axis_stride = 1; d[2].out_col_stride = Nx; d[2].out_b1_stride = vz; d[2].out_contig = 1;
+      d[1].in_axis_stride = Nx; d[1].in_col_stride = 1; d[1].in_b1_stride = vz; d[1].in_contig = 0;
+      d[1].out_axis_stride = 1; d[1].out_col_stride = wx; d[1].out_b1_stride = wy; d[1].out_contig = 1;
+      d[0].in_axis_stride = wy; d[0].in_col_stride = 1; d[0].in_b1_stride = wx; d[0].in_contig = 0;
+      d[0].out_axis_stride = 1; d[0].out_col_stride = is1; d[0].out_b1_stride = is0; d[0].out_contig = 1;
+      t = d[0]; d[0] = d[2]; d[2] = t; /* launch order x, y, z */
+      src[0] = data; dst[0] = V; src[1] = V; dst[1] = W; src[2] = W; dst[2] = data;
+      slot[0] = 2; slot[1] = 1; slot[2] = 0;
+    }
   } else {
-    /* y-z-x output (is_equalxy): z and y passes in the natural layout inside W,
+    /* y-z-x output (is_equalxy), one scratch volume: z and y passes in the natural layout inside W,
      * the x pass transposes into the caller's layout */
     const long long w1 = Nz, w0 = (long long)Ny * Nz;
     desc_init(&d[0], st, Nzf, dir, 2);
@@ -1783,7 +1827,8 @@ static int execute_single(struct _offt_plan *po, void *data, int dir) {
   int ia = -1, cnt = 0;       /* producer launch (the consumer is the next one); planes the two share */
   double plane_elems = 0.0;
   int len_a = 0, len_b = 0;   /* their line lengths */
-  if (zyx) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
+  /* (the rotating y-z-x schedule has the same y / x pair over z-planes as z-y-x) */
+  if (zyx || yzx_rot) { ia = dir < 0 ? 1 : 0; cnt = Nz; plane_elems = (double)Nx * Ny; len_a = dir < 0 ? Ny : Nx; len_b = dir < 0 ? Nx : Ny; }
   /* (the rotating x-y-z schedule runs its three launches plainly: P1 and P2 do share y-planes of W, but alternating them
    * over groups of planes -- the consumer sliced along its columns -- came out SLOWER, 17.9 against 17.4 ms at 1024^3 f64,
    * profiles/r03_layouts.txt) */

@@ -78,13 +78,16 @@ def test_single_rank_zgroups(cpu1, monkeypatch, streams):
         assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
         roundtrip_ok(**kw)
     # a CUBE: every pass has the same batch count, so a wrongly chosen pair of launches would still "match" and alternate
-    for kw in (dict(), dict(S=1), dict(is_equalxy=1)):
+    for kw in (dict(), dict(S=1), dict(is_equalxy=1), dict(is_equalxy=1, rotate=1), dict(S=1, rotate=1)):
         shape = (64, 64, 64)
+        kw = dict(kw)
+        monkeypatch.setenv("OFFT_ROTATE", str(kw.pop("rotate", 0)))
         c, v, buf = cpu_world.run_rank(*shape, **kw)
         G = np.zeros(shape, dtype=np.complex128)
         cpu_world.scatter_out(c, buf, G)
         assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL, kw
         roundtrip_ok(**kw)
+    monkeypatch.delenv("OFFT_ROTATE")
     shape = (64, 64, 38)  # r2c: 20 planes of the half spectrum
     c, v, buf = cpu_world.run_rank(*shape, is_r2c=1)
     G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
@@ -92,12 +95,12 @@ def test_single_rank_zgroups(cpu1, monkeypatch, streams):
     assert rel(G, np.fft.rfftn(O.hash_field(*shape).real)) < TOL
 
 
-@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 8, 4), (6, 10, 9), (32, 2, 3)])
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 8, 4), (6, 10, 9), (32, 2, 3), (12, 12, 10)])
 def test_single_rank_xyz_rotating_schedule(cpu1, monkeypatch, shape):
     """x-y-z output (S = 1) through the rotating three-pass schedule (two scratch volumes, the x pass in the middle); the
-    library picks it when an x-plane is a whole number of MiB, OFFT_S1_INPLACE=0 forces it for these small grids.
-    Forward, inverse round trip, r2c."""
-    monkeypatch.setenv("OFFT_S1_INPLACE", "0")
+    library picks it when an x-plane is a whole number of MiB, OFFT_ROTATE=1 forces it for these small grids.
+    Forward, inverse round trip, r2c; and the y-z-x layout's rotating schedule (is_equalxy, Nx == Ny) the same way."""
+    monkeypatch.setenv("OFFT_ROTATE", "1")
     c, v, buf, back = cpu_world.run_rank(*shape, S=1, roundtrip=True)
     G = np.zeros(shape, dtype=np.complex128)
     cpu_world.scatter_out(c, buf, G)
@@ -107,6 +110,17 @@ def test_single_rank_xyz_rotating_schedule(cpu1, monkeypatch, shape):
     G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
     cpu_world.scatter_out(c, buf, G)
     assert rel(G, np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2))) < TOL
+    if shape[0] == shape[1]:
+        c, v, buf, back = cpu_world.run_rank(*shape, is_equalxy=1, roundtrip=True)
+        assert c["ostride"] == [1, shape[0] * shape[2], shape[0]]
+        G = np.zeros(shape, dtype=np.complex128)
+        cpu_world.scatter_out(c, buf, G)
+        assert rel(G, np.fft.fftn(O.hash_field(*shape))) < TOL
+        assert rel(cpu_world.input_block(c, back) / np.prod(shape), O.hash_field(*shape)) < TOL
+        c, v, buf = cpu_world.run_rank(*shape, is_equalxy=1, is_r2c=1)
+        G = np.zeros((shape[0], shape[1], shape[2] // 2 + 1), dtype=np.complex128)
+        cpu_world.scatter_out(c, buf, G)
+        assert rel(G, np.fft.rfftn(O.hash_field(*shape).real, axes=(0, 1, 2))) < TOL
 
 
 def test_single_rank_forced_pipeline(cpu1, monkeypatch):

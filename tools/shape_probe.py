@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer perf probe for one (possibly non-cubic) grid on one GPU: per-pass device time and fraction of the
-HBM roofline.   tools/shape_probe.py Nx,Ny,Nz [f64|f32] [S] [reps] [vx,vy,vz]
+HBM roofline.   tools/shape_probe.py Nx,Ny,Nz [f64|f32] [S] [reps] [vx,vy,vz] [eq]
 Each pass moves 2 * esz * E bytes; the pass of axis length n is reported with its kernel name."""
 import ctypes as C
 import math
@@ -46,4 +46,5 @@ if __name__ == "__main__":
     S = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     var = tuple(int(x) for x in sys.argv[5].split(",")) if len(sys.argv) > 5 else (-1, -1, -1)
-    run(shape, prec, S, reps, var)
+    eq = int(sys.argv[6]) if len(sys.argv) > 6 else 0   # 1: is_equalxy (y-z-x output, Nx == Ny)
+    run(shape, prec, S, reps, var, eq)
