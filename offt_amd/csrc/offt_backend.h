@@ -60,6 +60,12 @@ void offt_hip_test_set_backend(const offt_backend *b, int rank, int size);
 typedef int (*offt_test_transport_fn)(int which, int npeers, const int *peer, const void *const *sendp,
                                       const size_t *sendbytes, void *const *recvp, const size_t *recvbytes);
 void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size);
+/* ... the same, but ASYNCHRONOUS: `fn` is called without draining the stream and gets it as its last argument; it has to
+ * enqueue the copies itself (ordered by events between the ranks' streams), so that the schedules' own event edges between
+ * compute and comm streams are all that orders kernels and exchanges -- as with RCCL.  Set after offt_hip_test_set_transport. */
+typedef int (*offt_test_transport_async_fn)(int which, int npeers, const int *peer, const void *const *sendp, const size_t *sendbytes,
+                                            void *const *recvp, const size_t *recvbytes, void *stream);
+void offt_hip_test_set_transport_async(offt_test_transport_async_fn fn);
 /* several ranks as threads of ONE process (one GPU, or the CPU backend): hipIpc cannot open a handle in the process that
  * made it, so peer_open goes through `fn` (same arguments as offt_backend::peer_open without ctx), which hands out the
  * other threads' pointers; `hook` is called before every wait the direct-store schedule enqueues -- a barrier among the

@@ -109,6 +109,8 @@ int offt_hipk_fill(void *buf, int precision, int kind,
 int offt_hipk_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream);
 int offt_hipk_flag_wait(int n, unsigned long long *const *addr, unsigned long long value, unsigned long long *status,
                         double timeout_s, void *stream);
+/* one wave that holds `stream` for `ms` milliseconds (used by test builds to make the device lag behind the host) */
+int offt_hipk_delay(double ms, void *stream);
 const char *offt_hipk_last_error(void);
 
 #ifdef __cplusplus

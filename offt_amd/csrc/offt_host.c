@@ -468,6 +468,14 @@ static int hb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
     fprintf(stderr, "offt-pass %s n %d ncols %d nb1 %d nb2 %d prec %d in_contig %d out_contig %d in_split %d out_split %d elems %lld\n",
             offt_hipk_kernel_name(d), d->n, d->ncols, d->nb1, d->nb2, d->precision, d->in_contig, d->out_contig, d->in_split,
             d->out_split, (long long)d->n * d->ncols * d->nb1 * d->nb2);
+#ifdef OFFT_TEST_SEAMS
+  /* test build: OFFT_TEST_SLOW_PASS_MS=<ms> holds the stream that long in front of every pass, so that the device lags behind
+   * the host and an exchange that does not wait for the kernel that packs its data really reads too early
+   * (tools/async_negative_control.sh) */
+  static double slow_ms = -1.0;
+  if (slow_ms < 0) slow_ms = getenv("OFFT_TEST_SLOW_PASS_MS") ? atof(getenv("OFFT_TEST_SLOW_PASS_MS")) : 0.0;
+  if (slow_ms > 0 && d->n > 0 && d->ncols > 0 && d->nb1 > 0 && d->nb2 > 0) (void)offt_hipk_delay(slow_ms, stream);
+#endif
   int rc = offt_hipk_fft_pass(d, in, out, stream);
   if (rc) SET_ERR("pass n=%d failed: %s", d->n, offt_hipk_last_error());
   return rc;
@@ -506,8 +514,11 @@ void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size) 
   G_tls_on = fn != NULL;
   if (fn) { memset(&G_tls, 0, sizeof G_tls); G_tls.rank = rank; G_tls.size = size; }
 }
+static _Thread_local offt_test_transport_async_fn g_test_transport_async = NULL;
+void offt_hip_test_set_transport_async(offt_test_transport_async_fn fn) { g_test_transport_async = fn; }
 #else
 #define g_test_transport ((offt_test_transport_fn)NULL)
+#define g_test_transport_async ((offt_test_transport_async_fn)NULL)
 #endif
 
 /* all-to-all of one tile inside a row/column group (communicate_a2a(v),
@@ -515,6 +526,8 @@ void offt_hip_test_set_transport(offt_test_transport_fn fn, int rank, int size) 
 static int hb_a2a(void *ctx, int which, int npeers, const int *peer_rank_in_comm, const void *const *sendp,
                   const size_t *sendbytes, void *const *recvp, const size_t *recvbytes, void *stream) {
   hip_state *st = (hip_state *)ctx;
+  if (g_test_transport && g_test_transport_async) /* the test enqueues the copies on `stream` itself: nothing is drained */
+    return g_test_transport_async(which, npeers, peer_rank_in_comm, sendp, sendbytes, recvp, recvbytes, stream);
   if (g_test_transport) { /* synchronous, host-staged by the test */
     /* (a rehearsal transport that moves nothing may skip the host synchronisation: OFFT_TEST_TRANSPORT_NOSYNC=1) */
     static int nosync = -1;
@@ -1951,6 +1964,23 @@ static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const voi
   return 0;
 }
 
+/* The event edges between compute and comm streams that the multi-rank schedules rest on, numbered.  In the test build
+ * OFFT_TEST_DROP_EDGE=<id> leaves one class of them out: the negative control of the asynchronous-transport tests
+ * (tools/async_negative_control.sh) -- with the edge gone the result must come out wrong, which shows both that the
+ * edge is needed and that the tests would notice its absence.  The product build has no such switch. */
+enum { EDGE_SLAB_K2_AFTER_EXCHANGE = 1, EDGE_SLAB_EXCHANGE_AFTER_K1 = 2, EDGE_PENCIL_EX1_AFTER_K1 = 3, EDGE_PENCIL_K2_AFTER_EX1 = 4,
+       EDGE_PENCIL_EX2_AFTER_K2 = 5, EDGE_PENCIL_K3_AFTER_EX2 = 6, EDGE_INV_EXCHANGE_AFTER_PASSES = 7, EDGE_INV_K1_AFTER_EXCHANGES = 8 };
+#ifdef OFFT_TEST_SEAMS
+static int edge_dropped(int id) {
+  static int drop = -1;
+  if (drop < 0) drop = getenv("OFFT_TEST_DROP_EDGE") ? atoi(getenv("OFFT_TEST_DROP_EDGE")) : 0;
+  return drop == id;
+}
+#define SCHED_WAIT(id, stream, ev) do { if (!edge_dropped(id)) be->stream_wait((stream), (ev)); } while (0)
+#else
+#define SCHED_WAIT(id, stream, ev) be->stream_wait((stream), (ev))
+#endif
+
 /* flag operations of the direct-store exchange.  Recorded (multi-rank inverse) they become plain sync points: the
  * mirrored schedule puts a barrier of the group wherever the forward schedule signals or waits -- every dependency of the
  * forward schedule crosses at least one of these points, so its mirror image is ordered by the barriers. */
@@ -1993,7 +2023,7 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   for (int pass = 0; pass < (overlap ? st->sH + 1 : 1) && !rc; pass++) {
    const int want_tag = overlap ? (pass < st->sH ? st->sH - 1 - pass : -1) : 0; /* chunks H-1 .. 0, then the K1 phase */
    int chunk_exchanged = 0;
-   if (overlap && want_tag < 0) be->stream_wait(s, st->ev_s1[0]); /* every exchange has landed */
+   if (overlap && want_tag < 0) SCHED_WAIT(EDGE_INV_K1_AFTER_EXCHANGES, s, st->ev_s1[0]); /* every exchange has landed */
    for (int kind_turn = 0; kind_turn < (overlap ? 2 : 1) && !rc; kind_turn++) /* a chunk's passes first, then its exchanges */
    for (int i = L.n - 1; i >= 0 && !rc; i--) {
     step *e = &L.v[i];
@@ -2003,7 +2033,7 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
       if ((e->kind == 1) != (kind_turn == 1)) continue;
       if (e->kind == 1) {
         sx = st->s_comm1;
-        if (!chunk_exchanged) { be->event_record(st->ev_sa[want_tag], s); be->stream_wait(sx, st->ev_sa[want_tag]); chunk_exchanged = 1; }
+        if (!chunk_exchanged) { be->event_record(st->ev_sa[want_tag], s); SCHED_WAIT(EDGE_INV_EXCHANGE_AFTER_PASSES, sx, st->ev_sa[want_tag]); chunk_exchanged = 1; }
       }
     }
     if (e->kind == 0) {
@@ -2210,7 +2240,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       for (int g = 0; g < groups; g++) {
         int cnt = 0;
         const void *sp[per * p2]; void *rp[per * p2]; size_t sb[per * p2], rb[per * p2]; int pr[per * p2];
-        if (h == 0) be->stream_wait(sc, st->ev_s1[g]);
+        if (h == 0) SCHED_WAIT(EDGE_SLAB_EXCHANGE_AFTER_K1, sc, st->ev_s1[g]);
         for (int ii = 0; ii < per; ii++) {
           const int i = (h == 0) ? g : ii;
           for (int a = 0; a < p2; a++) {
@@ -2236,7 +2266,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
     const int z0 = h * Tz;
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;           /* planes of this chunk in a (padded) peer block */
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh; if (nz < 0) nz = 0; /* ... of which this rank owns nz */
-    if (st->x1 && !p2p) be->stream_wait(s, st->ev_sa[h]);
+    if (st->x1 && !p2p) SCHED_WAIT(EDGE_SLAB_K2_AFTER_EXCHANGE, s, st->ev_sa[h]);
     /* ---- K2(h): unpack1 + FFTy (offt-compute.c:1208-1520) into R2[z_l][y][x] ---- */
     if (nz > 0) {
       const char *src = (const char *)(st->x1 ? st->R1 : st->S1) + (st->slab_yc ? (size_t)h * st->sBc : (size_t)z0 * c->M2 * T) * esz;
@@ -2371,7 +2401,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       if (pp1) {
         if (run_signal(st, &st->g1, r, st->use1[r], s)) return -1;
       } else if (st->x1) {
-        be->stream_wait(st->s_comm1, st->ev_k1[r]);
+        SCHED_WAIT(EDGE_PENCIL_EX1_AFTER_K1, st->s_comm1, st->ev_k1[r]);
         const void *sp[p2]; void *rp[p2]; size_t sb[p2], rb[p2]; int pr[p2], cnt = 0;
         for (int a = 0; a < p2; a++) {
           if (st->tab_r1 && a == po->rank % p2) continue; /* K1 stored this rank's own block straight into recv1[r] */
@@ -2391,7 +2421,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
       if (pp1) { if (run_wait(st, &st->g1, r, st->use1[r], s)) return -1; }
-      else if (st->x1) be->stream_wait(s, st->ev_a1[r]);
+      else if (st->x1) SCHED_WAIT(EDGE_PENCIL_K2_AFTER_EX1, s, st->ev_a1[r]);
       if (pp2 && k == 0 && run_wait(st, &st->g2, 1, ep - 1, s)) return -1; /* the column peers have consumed the previous transform's recv2 */
       if (st->pencil_yc && myT > 0) {
         /* whole y-lines out of the receive blocks [x_t][z_l][y_l] (runs of F2 per peer), columns = x_t, into the
@@ -2449,7 +2479,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
        * grouped call, except for the last tile: there each chunk is its own call with an event behind it, so that
        * K3(h) can start while chunks h+1.. are still on the wire ---- */
       if (st->x2 && !pp2) {
-        be->stream_wait(st->s_comm2, st->ev_k2[r]);
+        SCHED_WAIT(EDGE_PENCIL_EX2_AFTER_K2, st->s_comm2, st->ev_k2[r]);
         const int last = (k == st->ntiles - 1);
         const int merged = st->pencil_yc && !last; /* one contiguous message per peer holds every chunk of the tile */
         const int ngroups = last ? H : 1, per = (last || merged) ? 1 : H;
@@ -2489,7 +2519,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     const int z0 = h * Tz;
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh;
-    if (st->x2 && !pp2) be->stream_wait(s, st->ev_a2[w2 == 0 ? H - 1 : h]);
+    if (st->x2 && !pp2) SCHED_WAIT(EDGE_PENCIL_K3_AFTER_EX2, s, st->ev_a2[w2 == 0 ? H - 1 : h]);
     if (nz <= 0 || c->m4 <= 0) continue;
     offt_pass_desc d;
     desc_init(&d, st, Nx, dir, 0);

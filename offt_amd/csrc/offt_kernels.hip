@@ -1315,6 +1315,23 @@ int flag_launch(bool wait, int n, unsigned long long *const *addr, unsigned long
 }
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(64) delay_k(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+// one wave that holds `stream` for `ms` milliseconds (100 MHz constant clock; at most 1 s): test builds put it in front of
+// their passes to make the device lag behind the host (offt_host.c, OFFT_TEST_SLOW_PASS_MS)
+int offt_hipk_delay(double ms, void *stream) {
+  if (ms <= 0) return 0;
+  if (ms > 1000.0) ms = 1000.0;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(delay_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(ms * 1e5));
+  HIPK_CHECK(hipGetLastError());
+  return 0;
+}
+
 int offt_hipk_flag_signal(int n, unsigned long long *const *addr, unsigned long long value, void *stream) {
   return flag_launch(false, n, addr, value, nullptr, 0.0, stream);
 }

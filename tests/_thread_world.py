@@ -7,6 +7,13 @@ swapped: a rank "sends" by posting its device pointer, the receiver copies devic
 one device).
 backend cpu: the same host logic on the test-only CPU descriptor interpreter (tests/cpu_backend.c), host memory.
 
+A case with "async": 1 (gpu) runs the staged exchange through an ASYNCHRONOUS transport: nothing is drained on the host --
+the sender records an event on its comm stream, the receiver makes ITS comm stream wait for that event, enqueues the
+device-to-device copy there and records an event of its own, which the sender's comm stream waits for before it goes on
+(a send "completes" when the data has left the buffer, as with RCCL).  The host only hands pointers and events round;
+on the device the schedules' own event edges between compute and comm streams are all that orders kernels and copies, so a
+missing edge shows up as a wrong result instead of being hidden by a host synchronisation.
+
 A case with "p2p": 1 runs the DIRECT-STORE exchange (OFFT_EXCHANGE=p2p): no transport at all for the data -- the packing
 kernels of one rank store straight into the other ranks' receive volumes (another thread's buffer: a peer's memory) and
 flag kernels order the streams.  hipIpc cannot open a handle inside the process that made it, so peer_open goes through a
@@ -79,6 +86,15 @@ def main():
         torch.cuda.set_device(0)
         hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        hip.hipEventDestroy.argtypes = [C.c_void_p]
+        L.offt_hip_test_set_transport_async.argtypes = [C.c_void_p]
+        L.offt_hip_test_set_transport_async.restype = None
+    ASYNC_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
     wire = Wire()
     results, errors = {}, []
     tls = threading.local()   # the CPU backend's callbacks are process-wide: the calling thread knows its rank
@@ -155,7 +171,59 @@ def main():
                 return -1
         return transport
 
+    garbage = []  # events stay alive until the case is over (another rank's stream may still wait on them)
+
+    def new_event(stream):
+        ev = C.c_void_p()
+        if hip.hipEventCreateWithFlags(C.byref(ev), 2) != 0 or hip.hipEventRecord(ev, stream) != 0:  # hipEventDisableTiming
+            raise RuntimeError("event")
+        garbage.append(ev)
+        return ev
+
+    def make_async_transport(rank):
+        def transport(which, npeers, peer_in_group, sendp, sendbytes, recvp, recvbytes, stream):
+            try:
+                p1 = L.offt_hip_test_current_p1()
+                ready = new_event(stream)  # everything this rank's comm stream waited for (the packing kernel) lies before it
+                # a SLOW wire: a millisecond of spinning on this rank's comm stream ahead of its copies.  The host runs ahead
+                # of the device, so a kernel that does not wait for its exchange really starts before the data is there
+                # (tools/async_negative_control.sh: with the edge "K2 waits for its chunk" dropped the result is wrong)
+                # ("async": 2 leaves the wire fast: together with passes that are made slow -- OFFT_TEST_SLOW_PASS_MS, test
+                # build -- an exchange that does not wait for the kernel packing its data reads too early)
+                if tls.async_mode == 1:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                        torch.cuda._sleep(2_000_000)
+                acks = []
+                for a in range(npeers):
+                    if sendbytes[a]:
+                        peer = cpu_world.group_peer(which, peer_in_group[a], rank, size, p1)
+                        box = {}
+                        acks.append((wire.post((which, rank, peer), (sendp[a], ready, box), sendbytes[a]), box))
+                for a in range(npeers):
+                    if recvbytes[a]:
+                        peer = cpu_world.group_peer(which, peer_in_group[a], rank, size, p1)
+                        (ptr, peer_ready, box), nb, ack = wire.take((which, peer, rank))
+                        assert nb == recvbytes[a], (which, peer, rank, nb, recvbytes[a])
+                        if os.environ.get("OFFT_TEST_ASYNC_NOCOPY"):  # (sensitivity check of the harness itself: nothing arrives)
+                            pass
+                        elif hip.hipStreamWaitEvent(stream, peer_ready, 0) != 0 or hip.hipMemcpyAsync(recvp[a], ptr, nb, 3, stream) != 0:
+                            raise RuntimeError("async copy")
+                        box["done"] = new_event(stream)  # the sender's buffer has been read once this event has passed
+                        ack.set()
+                for ack, box in acks:
+                    if not ack.wait(120.0):
+                        raise RuntimeError("send not consumed")
+                    if hip.hipStreamWaitEvent(stream, box["done"], 0) != 0:  # my send is complete when the receiver has copied
+                        raise RuntimeError("wait")
+                return 0
+            except Exception as e:
+                print("async transport failed on rank", rank, repr(e), flush=True)
+                wire.fail()
+                return -1
+        return transport
+
     transports = {r: make_transport(r) for r in range(size)}
+    async_cbs = {}
     cpu_a2a = cpu_world.A2A_CB(lambda *a: transports[tls.rank](*a))  # CPU backend: ONE process-wide callback
 
     def unseam():
@@ -163,6 +231,7 @@ def main():
         if cpu:
             L.offt_hip_test_set_backend(None, 0, 1)
         else:
+            L.offt_hip_test_set_transport_async(None)
             L.offt_hip_test_set_transport(None, 0, 1)
 
     def rank_thread(rank, ci, case, bar):
@@ -173,6 +242,10 @@ def main():
             else:
                 cb = cpu_world.A2A_CB(transports[rank])
                 L.offt_hip_test_set_transport(C.cast(cb, C.c_void_p), rank, size)
+                if case.get("async"):
+                    tls.async_mode = int(case["async"])
+                    async_cbs[rank] = ASYNC_CB(make_async_transport(rank))
+                    L.offt_hip_test_set_transport_async(C.cast(async_cbs[rank], C.c_void_p))
             if case.get("p2p"):
                 L.offt_hip_test_set_p2p(C.cast(peer_cb, C.c_void_p), C.cast(hook_cb, C.c_void_p))
             prec = api.F32 if case.get("f32") else api.F64
@@ -312,6 +385,11 @@ def main():
         for k in case.get("env", {}):
             os.environ.pop(k, None)
         os.environ.pop("OFFT_EXCHANGE", None)
+        if not cpu:
+            torch.cuda.synchronize()
+            for ev in garbage:
+                hip.hipEventDestroy(ev)
+            del garbage[:]
         if errors:
             print("FAILED", errors, flush=True)
             sys.exit(1)
