@@ -473,8 +473,12 @@ static int hb_pass(const offt_pass_desc *d, const void *in, void *out, void *str
    * the host and an exchange that does not wait for the kernel that packs its data really reads too early
    * (tools/async_negative_control.sh) */
   static double slow_ms = -1.0;
-  if (slow_ms < 0) slow_ms = getenv("OFFT_TEST_SLOW_PASS_MS") ? atof(getenv("OFFT_TEST_SLOW_PASS_MS")) : 0.0;
-  if (slow_ms > 0 && d->n > 0 && d->ncols > 0 && d->nb1 > 0 && d->nb2 > 0) (void)offt_hipk_delay(slow_ms, stream);
+  static int slow_odd = 0; /* OFFT_TEST_SLOW_RANKS=odd: only the odd ranks are slow, so that the even ones run ahead of them */
+  if (slow_ms < 0) {
+    slow_odd = getenv("OFFT_TEST_SLOW_RANKS") && !strcmp(getenv("OFFT_TEST_SLOW_RANKS"), "odd");
+    slow_ms = getenv("OFFT_TEST_SLOW_PASS_MS") ? atof(getenv("OFFT_TEST_SLOW_PASS_MS")) : 0.0;
+  }
+  if (slow_ms > 0 && (!slow_odd || (G.rank & 1)) && d->n > 0 && d->ncols > 0 && d->nb1 > 0 && d->nb2 > 0) (void)offt_hipk_delay(slow_ms, stream);
 #endif
   int rc = offt_hipk_fft_pass(d, in, out, stream);
   if (rc) SET_ERR("pass n=%d failed: %s", d->n, offt_hipk_last_error());
@@ -1969,7 +1973,9 @@ static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const voi
  * (tools/async_negative_control.sh) -- with the edge gone the result must come out wrong, which shows both that the
  * edge is needed and that the tests would notice its absence.  The product build has no such switch. */
 enum { EDGE_SLAB_K2_AFTER_EXCHANGE = 1, EDGE_SLAB_EXCHANGE_AFTER_K1 = 2, EDGE_PENCIL_EX1_AFTER_K1 = 3, EDGE_PENCIL_K2_AFTER_EX1 = 4,
-       EDGE_PENCIL_EX2_AFTER_K2 = 5, EDGE_PENCIL_K3_AFTER_EX2 = 6, EDGE_INV_EXCHANGE_AFTER_PASSES = 7, EDGE_INV_K1_AFTER_EXCHANGES = 8 };
+       EDGE_PENCIL_EX2_AFTER_K2 = 5, EDGE_PENCIL_K3_AFTER_EX2 = 6, EDGE_INV_EXCHANGE_AFTER_PASSES = 7, EDGE_INV_K1_AFTER_EXCHANGES = 8,
+       /* ... and the two kinds of flag wait of the direct-store exchange */
+       EDGE_P2P_WAIT_READY = 9, EDGE_P2P_WAIT_FREE = 10 };
 #ifdef OFFT_TEST_SEAMS
 static int edge_dropped(int id) {
   static int drop = -1;
@@ -1979,6 +1985,7 @@ static int edge_dropped(int id) {
 #define SCHED_WAIT(id, stream, ev) do { if (!edge_dropped(id)) be->stream_wait((stream), (ev)); } while (0)
 #else
 #define SCHED_WAIT(id, stream, ev) be->stream_wait((stream), (ev))
+#define edge_dropped(id) 0
 #endif
 
 /* flag operations of the direct-store exchange.  Recorded (multi-rank inverse) they become plain sync points: the
@@ -1989,8 +1996,10 @@ static int run_signal(hip_state *st, p2p_group *g, int slot, unsigned long long 
   if (st->rec) { step *e = rec_new(st->rec); e->kind = 2; e->which = g->which; return 0; }
   return p2p_signal(st, g, slot, value, stream);
 }
-static int run_wait(hip_state *st, p2p_group *g, int slot, unsigned long long value, void *stream) {
+static int run_wait(hip_state *st, p2p_group *g, int slot, unsigned long long value, void *stream, int edge) {
+  (void)edge;
   if (st->skip_mask & 2) return 0;
+  if (!st->rec && edge_dropped(edge)) return 0; /* (test build: negative control, every rank drops the same waits) */
   if (st->rec) { step *e = rec_new(st->rec); e->kind = 2; e->which = g->which; return 0; }
   return p2p_wait(st, g, slot, value, stream);
 }
@@ -2180,7 +2189,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
   const int p2p = st->p2p && st->x1;
   /* (a schedule that is only being RECORDED for the mirrored inverse issues no flag operation and must not count one) */
   const unsigned long long ep = (p2p && !st->rec) ? ++st->epoch : 0;
-  if (p2p && run_wait(st, &st->g1, 1, ep - 1, s)) return -1;
+  if (p2p && run_wait(st, &st->g1, 1, ep - 1, s, EDGE_P2P_WAIT_FREE)) return -1;
 
   /* ---- K1: FFTz + pack (offt-compute.c:905-1206), all x-tiles ---- */
   be->event_record(st->evp[0], s);
@@ -2227,7 +2236,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
    * wire, chunk h lands at about t_K1(0) + (h+1) C/H and is needed at t_K1 + h (t_K2+t_K3)/H:
    * the wire is never idle and compute only waits if the links are the bottleneck. ---- */
   if (p2p) {
-    if (run_signal(st, &st->g1, 0, ep, s) || run_wait(st, &st->g1, 0, ep, s)) return -1;
+    if (run_signal(st, &st->g1, 0, ep, s) || run_wait(st, &st->g1, 0, ep, s, EDGE_P2P_WAIT_READY)) return -1;
   } else if (st->x1) {
     for (int h = 0; h < H; h++) {
       st->rec_tag = h;
@@ -2371,7 +2380,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
       if (i >= st->ring) be->stream_wait(s, st->ev_k2[r]); /* slot's previous tile fully consumed */
       if (pp1) { /* ... by every row peer: they read what this rank stored into THEIR slot r */
-        if (run_wait(st, &st->g1, st->ring + r, st->use1[r], s)) return -1;
+        if (run_wait(st, &st->g1, st->ring + r, st->use1[r], s, EDGE_P2P_WAIT_FREE)) return -1;
         if (!st->rec) st->use1[r]++;
       }
       if (myT > 0 && c->m2 > 0) {
@@ -2420,9 +2429,9 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- K2(k): unpack1 + FFTy (+ pack2) (offt-compute.c:1208-1520, 1636-2345) ---- */
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
-      if (pp1) { if (run_wait(st, &st->g1, r, st->use1[r], s)) return -1; }
+      if (pp1) { if (run_wait(st, &st->g1, r, st->use1[r], s, EDGE_P2P_WAIT_READY)) return -1; }
       else if (st->x1) SCHED_WAIT(EDGE_PENCIL_K2_AFTER_EX1, s, st->ev_a1[r]);
-      if (pp2 && k == 0 && run_wait(st, &st->g2, 1, ep - 1, s)) return -1; /* the column peers have consumed the previous transform's recv2 */
+      if (pp2 && k == 0 && run_wait(st, &st->g2, 1, ep - 1, s, EDGE_P2P_WAIT_FREE)) return -1; /* the column peers have consumed the previous transform's recv2 */
       if (st->pencil_yc && myT > 0) {
         /* whole y-lines out of the receive blocks [x_t][z_l][y_l] (runs of F2 per peer), columns = x_t, into the
          * column-exchange volume [chunk][peer][x-tile][z in chunk][y_l][x_t]: x contiguous, one (chunk, peer, tile)
@@ -2513,7 +2522,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     }
   }
   be->event_record(st->evp[2], s);
-  if (pp2 && run_wait(st, &st->g2, 0, st->tiles2, s)) return -1; /* every column peer has stored all its tiles (they count like this rank) */
+  if (pp2 && run_wait(st, &st->g2, 0, st->tiles2, s, EDGE_P2P_WAIT_READY)) return -1; /* every column peer has stored all its tiles (they count like this rank) */
   /* ---- K3(h): unpack2 + FFTx into the caller's layout (offt-compute.c:2347-2993), z-chunk by z-chunk ---- */
   for (int h = 0; h < H; h++) {
     const int z0 = h * Tz;

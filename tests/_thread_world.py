@@ -288,24 +288,30 @@ def main():
             api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
             res = {"comm": c, "v": v, "out": dev.cpu().numpy().view(ct).copy()}
             for rep_i in range(case.get("repeat", 0)):
-                # the same plan again on fresh input (buffer reuse between transforms: the FREE flags of the direct-store
-                # exchange); with "inv" in between: forward, inverse, forward on one plan
+                # the same plan again on OTHER input (buffer reuse between transforms: the FREE flags of the direct-store
+                # exchange; a block of the previous transform read in place of this one's would show): the field times
+                # 2^(i+1), exactly representable, so the result is the first one times 2^(i+1), bit for bit
                 if L.offt_hip_fill_input(po, dev.data_ptr(), 1):
                     raise RuntimeError("fill failed")
+                dev.mul_(2.0 ** (rep_i + 1))
+                torch.cuda.current_stream().synchronize()  # (this thread's stream only: a device-wide wait would line the ranks up)
                 api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
                 again = dev.cpu().numpy().view(ct)
-                if not np.array_equal(again, res["out"]):
-                    raise RuntimeError(f"repeat {rep_i}: result differs from the first transform")
+                if not np.array_equal(again, res["out"] * ct(2.0 ** (rep_i + 1))):
+                    raise RuntimeError(f"repeat {rep_i}: result differs from the first transform (times {2 ** (rep_i + 1)})")
             if case.get("inv"):
                 bar.wait()
                 api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
-                res["inv"] = cpu_world.input_block(c, dev.cpu().numpy().view(ct))
+                # (dev holds the LAST forward result: the field times 2^repeat)
+                res["inv"] = cpu_world.input_block(c, dev.cpu().numpy().view(ct)) / ct(2.0 ** case.get("repeat", 0))
                 if case.get("repeat"):
                     if L.offt_hip_fill_input(po, dev.data_ptr(), 1):
                         raise RuntimeError("fill failed")
+                    dev.mul_(0.5)
+                    torch.cuda.current_stream().synchronize()
                     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
-                    if not np.array_equal(dev.cpu().numpy().view(ct), res["out"]):
-                        raise RuntimeError("forward after inverse differs from the first transform")
+                    if not np.array_equal(dev.cpu().numpy().view(ct), res["out"] * ct(0.5)):
+                        raise RuntimeError("forward after inverse differs from the first transform (times 1/2)")
             bar.wait()
             api.offt_3d_fin(po)
             unseam()
@@ -343,11 +349,11 @@ def main():
         api.offt_3d_execute(po, ptr, ptr)
         res = {"comm": c, "v": v, "out": buf.copy()}
         for rep_i in range(case.get("repeat", 0)):
-            b2 = fill()
+            b2 = fill() * ct(2.0 ** (rep_i + 1))  # other data every time: see the GPU path
             p2 = b2.ctypes.data_as(C.c_void_p)
             api.offt_3d_execute(po, p2, p2)
-            if not np.array_equal(b2, res["out"]):
-                raise RuntimeError(f"repeat {rep_i}: result differs from the first transform")
+            if not np.array_equal(b2, res["out"] * ct(2.0 ** (rep_i + 1))):
+                raise RuntimeError(f"repeat {rep_i}: result differs from the first transform (times {2 ** (rep_i + 1)})")
         if case.get("inv"):
             back = buf.copy()
             bp = back.ctypes.data_as(C.c_void_p)

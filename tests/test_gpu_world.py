@@ -160,6 +160,20 @@ def test_direct_store_exchange_thread_worlds(built, tmp_path):
     assert s[1]["mesh"] == [2, 4]
     run_thread_world(3, [dict(N=[64, 64, 64], params=dict(P1=1), p2p=1, repeat=1), dict(N=[100, 96, 120], params=dict(P1=3), p2p=1, inv=1),
                          dict(N=[128, 100, 96], params=dict(P1=3), f32=1, p2p=1)], tmp_path)
+    # ... and with SLOW passes (the test build holds the stream 50 ms ahead of every pass): the host runs far ahead of the
+    # device, every READY / FREE wait really has to hold its stream -- plans reused, so that a rank's next transform stores
+    # into its peer's volume only after the peer has consumed the previous one
+    run_thread_world(2, [dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, repeat=2),
+                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=1, T2=16), p2p=1, repeat=2),
+                         dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, inv=1, repeat=1),
+                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=0, T2=16), p2p=1, inv=1, repeat=1)], tmp_path,
+                     env=dict(OFFT_TEST_SLOW_PASS_MS="50", OFFT_P2P_TIMEOUT="60"))
+    # ... and with only the ODD rank slow: the even rank runs a whole phase ahead of it.  In this world a dropped READY wait and
+    # a dropped FREE wait both come out as wrong results (tools/async_negative_control.sh, profiles/r03_async_negative_control.txt)
+    run_thread_world(2, [dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, repeat=2),
+                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=1, T2=16), p2p=1, repeat=2),
+                         dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, inv=1, repeat=1)], tmp_path,
+                     env=dict(OFFT_TEST_SLOW_PASS_MS="50", OFFT_TEST_SLOW_RANKS="odd", OFFT_P2P_TIMEOUT="60"))
 
 
 def test_direct_store_exchange_full_size_eight_ranks_one_gpu(built, tmp_path):

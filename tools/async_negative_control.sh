@@ -22,5 +22,13 @@ echo "--- edge 2 (slab:exchange-after-K1) DROPPED, slow passes:"; OFFT_TEST_SLOW
 echo "--- edge 3 (pencil:exchange1-after-K1) DROPPED, slow passes:"; OFFT_TEST_SLOW_PASS_MS=50 OFFT_TEST_DROP_EDGE=3 run "$(fast "$PENCIL1")"
 echo "--- edge 5 (pencil:exchange2-after-K2) DROPPED, slow passes:"; OFFT_TEST_SLOW_PASS_MS=50 OFFT_TEST_DROP_EDGE=5 run "$(fast "$PENCIL")"
 echo "--- edge 7 (inverse:exchange-after-its-passes) DROPPED, slow passes:"; OFFT_TEST_SLOW_PASS_MS=50 OFFT_TEST_DROP_EDGE=7 run "$(fast "$SLABINV")"
+# the direct-store exchange's flag waits, slow passes on the ODD rank only (the even rank runs ahead of it): READY ("the blocks are in my volume") and FREE ("overwrite what you stored")
+P2PSLAB='[{"N": [128, 128, 128], "params": {"P1": 1, "T1": 32, "T2": 16}, "p2p": 1, "repeat": 2}]'
+P2PPENCIL='[{"N": [128, 128, 128], "params": {"P1": 2, "T1": 16, "W1": 1, "T2": 16}, "p2p": 1, "repeat": 2}]'
+for c in "$P2PSLAB" "$P2PPENCIL"; do
+  echo "--- edge 9 (direct-store: wait READY) DROPPED, the odd rank slow:"; OFFT_TEST_SLOW_RANKS=odd OFFT_TEST_SLOW_PASS_MS=50 OFFT_TEST_DROP_EDGE=9 run "$c"
+  echo "--- edge 10 (direct-store: wait FREE) DROPPED, the odd rank slow:"; OFFT_TEST_SLOW_RANKS=odd OFFT_TEST_SLOW_PASS_MS=50 OFFT_TEST_DROP_EDGE=10 run "$c"
+  echo "--- direct-store, every wait in place, the odd rank slow:"; OFFT_TEST_SLOW_RANKS=odd OFFT_TEST_SLOW_PASS_MS=50 run "$c"
+done
 echo "--- every edge in place, slow wire:"; for c in "$SLAB" "$SLABINV" "$PENCIL" "$PENCIL1"; do run "$c"; done
 echo "--- every edge in place, slow passes:"; for c in "$SLAB" "$SLABINV" "$PENCIL" "$PENCIL1"; do OFFT_TEST_SLOW_PASS_MS=50 run "$(fast "$c")"; done
