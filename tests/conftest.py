@@ -22,3 +22,17 @@ def built():
     if not all(os.path.exists(n) for n in need):
         subprocess.check_call(["make", "-C", ROOT, "all", "tests/libcpubackend.so", "tests/liboffthip_test.so"])
     return True
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_cache(request):
+    """After every -m gpu test: hand the device memory PyTorch's caching allocator still holds back to the driver.  The
+    full-size tests leave up to 128 GiB cached in this process, and the multi-rank tests that follow run in SUBPROCESSES
+    (ranks as threads or processes sharing the card) that need the memory themselves."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available():
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
