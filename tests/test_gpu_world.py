@@ -163,16 +163,13 @@ def test_direct_store_exchange_thread_worlds(built, tmp_path):
     # ... and with SLOW passes (the test build holds the stream 50 ms ahead of every pass): the host runs far ahead of the
     # device, every READY / FREE wait really has to hold its stream -- plans reused, so that a rank's next transform stores
     # into its peer's volume only after the peer has consumed the previous one
-    run_thread_world(2, [dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, repeat=2),
-                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=1, T2=16), p2p=1, repeat=2),
-                         dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, inv=1, repeat=1),
-                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=0, T2=16), p2p=1, inv=1, repeat=1)], tmp_path,
+    run_thread_world(2, [dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=32), p2p=1, repeat=1),
+                         dict(N=[128, 128, 128], params=dict(P1=2, T1=32, W1=0, T2=32), p2p=1, inv=1)], tmp_path,
                      env=dict(OFFT_TEST_SLOW_PASS_MS="50", OFFT_P2P_TIMEOUT="60"))
     # ... and with only the ODD rank slow: the even rank runs a whole phase ahead of it.  In this world a dropped READY wait and
     # a dropped FREE wait both come out as wrong results (tools/async_negative_control.sh, profiles/r03_async_negative_control.txt)
     run_thread_world(2, [dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, repeat=2),
-                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=1, T2=16), p2p=1, repeat=2),
-                         dict(N=[128, 128, 128], params=dict(P1=1, T1=32, T2=16), p2p=1, inv=1, repeat=1)], tmp_path,
+                         dict(N=[128, 128, 128], params=dict(P1=2, T1=16, W1=1, T2=16), p2p=1, repeat=2)], tmp_path,
                      env=dict(OFFT_TEST_SLOW_PASS_MS="50", OFFT_TEST_SLOW_RANKS="odd", OFFT_P2P_TIMEOUT="60"))
 
 
@@ -202,30 +199,27 @@ def test_staged_exchange_with_an_asynchronous_transport(built, tmp_path):
     edge (a K2 that does not wait for its tile, a K1 that overwrites a send block still being read, the next transform
     running into the previous one's exchange) shows up as a wrong result.  Slab and pencil meshes of the bench, ragged
     grids, two comm streams, the mirrored inverse, plans used several times in a row."""
-    cases = [dict(N=[256, 256, 256], params=dict(P1=1), repeat=3, **{"async": 1}), dict(N=[256, 256, 256], params=dict(), repeat=3, **{"async": 1}),
-             dict(N=[256, 256, 256], params=dict(P1=8), repeat=2, **{"async": 1}),
-             dict(N=[256, 256, 256], params=dict(P1=2, T1=16, W1=1, T2=8), repeat=2, **{"async": 1}),
-             dict(N=[100, 72, 90], params=dict(P1=2, T1=7, T2=5), repeat=2, **{"async": 1}), dict(N=[100, 72, 90], params=dict(P1=1), inv=1, repeat=1, **{"async": 1}),
-             dict(N=[128, 128, 128], params=dict(), inv=1, repeat=2, **{"async": 1}), dict(N=[128, 128, 128], params=dict(P1=1), inv=1, repeat=2, **{"async": 1}),
-             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), repeat=2, env=dict(OFFT_COMM_STREAMS=2), **{"async": 1}),
-             dict(N=[128, 128, 128], params=dict(P1=4, T1=8, T2=16, W2=0), repeat=1, env=dict(OFFT_COMM_STREAMS=2), **{"async": 1}),
-             dict(N=[128, 128, 128], params=dict(P1=1, T1=16, T2=4), repeat=2, env=dict(OFFT_SELF_BYPASS=0), **{"async": 1}),
-             dict(N=[256, 256, 256], params=dict(P1=1), f32=1, repeat=2, **{"async": 1}), dict(N=[128, 128, 128], params=dict(P1=4, S=1, T2=8), repeat=1, **{"async": 1})]
+    cases = [dict(N=[256, 256, 256], params=dict(P1=1), repeat=2, **{"async": 1}), dict(N=[256, 256, 256], params=dict(), repeat=2, **{"async": 1}),
+             dict(N=[128, 128, 128], params=dict(P1=8), repeat=1, **{"async": 1}),
+             dict(N=[100, 72, 90], params=dict(P1=2, T1=7, T2=5), repeat=1, **{"async": 1}),
+             dict(N=[128, 128, 128], params=dict(), inv=1, repeat=1, **{"async": 1}), dict(N=[128, 128, 128], params=dict(P1=1), inv=1, repeat=1, **{"async": 1}),
+             dict(N=[128, 128, 128], params=dict(P1=2, T1=16, T2=8), repeat=1, env=dict(OFFT_COMM_STREAMS=2), **{"async": 1}),
+             dict(N=[128, 128, 128], params=dict(P1=1, T1=16, T2=4), repeat=1, env=dict(OFFT_SELF_BYPASS=0), **{"async": 1}),
+             dict(N=[128, 128, 128], params=dict(P1=1), f32=1, repeat=1, **{"async": 1})]
     run_thread_world(8, cases, tmp_path)
-    run_thread_world(3, [dict(N=[64, 100, 128], params=dict(P1=1), inv=1, repeat=2, **{"async": 1}), dict(N=[100, 96, 120], params=dict(P1=3), repeat=2, **{"async": 1})], tmp_path)
+    run_thread_world(3, [dict(N=[64, 100, 128], params=dict(P1=1), inv=1, repeat=1, **{"async": 1}), dict(N=[100, 96, 120], params=dict(P1=3), repeat=1, **{"async": 1})], tmp_path)
     # two ranks: the host threads get in each other's way least, so the device really runs behind the host -- this is the
     # world in which tools/async_negative_control.sh sees a dropped edge ("K2 waits for its chunk") as a wrong result
     # (profiles/r03_async_negative_control.txt; in an 8-thread world the slow host rendezvous hides it)
-    run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1), repeat=3, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=2), repeat=3, **{"async": 1}),
-                         dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=8), inv=1, repeat=2, **{"async": 1}),
-                         dict(N=[256, 128, 256], params=dict(P1=2, T1=16, W1=1, T2=16), inv=1, repeat=2, **{"async": 1}),
-                         dict(N=[256, 256, 256], params=dict(P1=1, S=1), repeat=2, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=1), f32=1, repeat=2, **{"async": 1})], tmp_path)
+    run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1), repeat=2, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=2), repeat=2, **{"async": 1}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=8), inv=1, repeat=1, **{"async": 1}),
+                         dict(N=[256, 128, 256], params=dict(P1=2, T1=16, W1=1, T2=16), inv=1, repeat=1, **{"async": 1}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, S=1), repeat=1, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=1), f32=1, repeat=1, **{"async": 1})], tmp_path)
     # the other half: a FAST wire ("async": 2) and SLOW passes (the test build holds the stream 50 ms ahead of every pass), so
     # that the host runs far ahead of the device and an exchange that did not wait for the kernel packing its data would
     # read too early.  All eight numbered edges of offt_host.c, dropped one at a time, come out wrong in these worlds:
     # profiles/r03_async_negative_control.txt
-    run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=16), repeat=1, **{"async": 2}),
-                         dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=16), inv=1, **{"async": 2}),
-                         dict(N=[256, 256, 256], params=dict(P1=2, T1=16, W1=1, T2=16), repeat=1, **{"async": 2}),
-                         dict(N=[256, 256, 256], params=dict(P1=1, S=1, T1=16, W1=1, T2=16), repeat=1, **{"async": 2})], tmp_path,
+    run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1, T1=64, T2=32), repeat=1, **{"async": 2}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, T1=64, T2=32), inv=1, **{"async": 2}),
+                         dict(N=[256, 256, 256], params=dict(P1=2, T1=32, W1=1, T2=32), repeat=1, **{"async": 2})], tmp_path,
                      env=dict(OFFT_TEST_SLOW_PASS_MS="50"))
