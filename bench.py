@@ -404,7 +404,9 @@ def rank_main(args):
     paired = int(L.offt_hip_last_passes_paired(po))
 
     def traffic_lookup(axis):
-        if not (os.path.exists(TRAFFIC_JSON) and world == 1 and n == 1024 and prec == api.F64 and not multi):
+        # recorded for THIS workload only (1024^3 f64, z-y-x, one rank) and for the z pass, a single launch per transform:
+        # the y / x records are per group launch (1/64 of a pass) and do not compare with alg_bytes_per_launch
+        if not (os.path.exists(TRAFFIC_JSON) and world == 1 and n == 1024 and prec == api.F64 and not multi and args.layout == "zyx" and axis == "z"):
             return None
         try:
             return json.load(open(TRAFFIC_JSON)).get(axis + "_pass_hbm_bytes_per_launch")
