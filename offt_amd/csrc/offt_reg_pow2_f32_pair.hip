@@ -14,6 +14,8 @@ void reg_pow2_f32_pair() {
   reg_variant_pair<2048, 16, 16, 16, 8, 8, true>(0, F_SS | F_CS | F_SC);
   reg_variant_pair<2048, 32, 32, 32, 2, 4, true>(1, F_CC);
   reg_variant_pair<2048, 32, 32, 32, 2, 8, true>(2, 0);
+  // (2048 on 4-pair panels -- two workgroups per CU, but 64-B segments on a strided side -- was tried again in round 3:
+  //  56.8 % against 62.5 % on the z pass of 2048 x 256 x 2048, profiles/r03_pair2048_cols4.txt; not registered)
   // 4096: the one-column kernel fits 4 columns (32-B segments on a strided side, 19 % of the roofline); 4 pairs move 64-B
   // segments: 54 % (profiles/r02_pair_4096.txt)
   reg_variant_pair<4096, 32, 32, 32, 4, 4, true>(0, F_ALL);
