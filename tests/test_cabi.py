@@ -82,7 +82,15 @@ def test_product_library_has_no_test_seams(built):
     dsyms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tools", "liboffthip_diag.so")]).decode()
     assert "offt_hip_set_debug_skip" in dsyms and "offt_hip_test_" not in dsyms
     tsyms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tests", "liboffthip_test.so")]).decode()
-    assert "offt_hip_test_set_backend" in tsyms and "offt_hip_test_set_transport" in tsyms
+    assert all(n in tsyms for n in ("offt_hip_test_set_backend", "offt_hip_test_set_transport", "offt_hip_test_set_transport_async", "offt_hip_test_set_p2p"))
+    # the negative-control switches of the ordering tests are compiled into the test build only
+    import mmap
+    with open(_lib.LIB_PATH, "rb") as f:
+        blob = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        assert blob.find(b"OFFT_TEST_DROP_EDGE") < 0 and blob.find(b"OFFT_TEST_SLOW_PASS_MS") < 0
+    with open(os.path.join(ROOT, "tests", "liboffthip_test.so"), "rb") as f:
+        blob = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        assert blob.find(b"OFFT_TEST_DROP_EDGE") >= 0
 
 
 def test_mpi_harness_compiles_and_links(built, tmp_path):
