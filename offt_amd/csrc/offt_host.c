@@ -397,6 +397,7 @@ typedef struct hip_state {
   int Tz2, H2;           /* pencil schedule, phase 2: z-chunk thickness (T2) and number of chunks of exchange 2 / FFTx */
   int pencil_yc;         /* pencil exchange volumes laid out y- / x-contiguous (two strided sides instead of four), see execute_pipeline() */
   void **ev_a2;          /* per z-chunk: the chunk's share of every x-tile has arrived (exchange 2) */
+  void **ev_t2;          /* per x-tile (mirrored pencil schedule): the tile's mirrored exchange 2 has landed */
   int uses_rccl;         /* this plan exchanges over RCCL communicators (watched while waiting) */
   int skip_mask;         /* diagnostics (offt_hip_set_debug_skip): 1 = no FFT passes, 2 = no exchanges */
   void **send1, **recv1; /* ring */
@@ -807,6 +808,8 @@ static void ring_teardown(hip_state *st) {
   st->ring = 0;
   for (int h = 0; h < st->H2 && st->ev_a2; h++) be->event_destroy(st->ev_a2[h]);
   free(st->ev_a2); st->ev_a2 = NULL;
+  for (int i = 0; i < st->ntiles && st->ev_t2; i++) be->event_destroy(st->ev_t2[i]);
+  free(st->ev_t2); st->ev_t2 = NULL;
   st->H2 = 0;
   if (st->send2 != st->recv2) be->dfree(st->send2);
   be->dfree(st->recv2);
@@ -881,6 +884,8 @@ static int ring_setup(struct _offt_plan *po, hip_state *st) {
   if (!st->recv2 || !st->send2) return -1;
   st->ev_a2 = (void **)calloc(st->H2, sizeof(void *));
   for (int h = 0; h < st->H2; h++) st->ev_a2[h] = be->event_create();
+  st->ev_t2 = (void **)calloc(st->ntiles, sizeof(void *));
+  for (int i = 0; i < st->ntiles; i++) st->ev_t2[i] = be->event_create();
   /* self blocks bypass the exchanges (see tab_self): K1 stores its own z-block into recv1[r], K2 its own y-block into recv2 */
   if (st->self_bypass && st->x1 && c->p2 > 1 && !st->p2p) {
     int ok = 1;
@@ -1975,7 +1980,11 @@ static int run_a2a(hip_state *st, int which, int cnt, const int *peer, const voi
 enum { EDGE_SLAB_K2_AFTER_EXCHANGE = 1, EDGE_SLAB_EXCHANGE_AFTER_K1 = 2, EDGE_PENCIL_EX1_AFTER_K1 = 3, EDGE_PENCIL_K2_AFTER_EX1 = 4,
        EDGE_PENCIL_EX2_AFTER_K2 = 5, EDGE_PENCIL_K3_AFTER_EX2 = 6, EDGE_INV_EXCHANGE_AFTER_PASSES = 7, EDGE_INV_K1_AFTER_EXCHANGES = 8,
        /* ... and the two kinds of flag wait of the direct-store exchange */
-       EDGE_P2P_WAIT_READY = 9, EDGE_P2P_WAIT_FREE = 10 };
+       EDGE_P2P_WAIT_READY = 9, EDGE_P2P_WAIT_FREE = 10,
+       /* ... and the mirrored pencil schedule's */
+       EDGE_INV_PENCIL_EX2_AFTER_K3 = 11, EDGE_INV_PENCIL_K2_AFTER_EX2 = 12, EDGE_INV_PENCIL_EX1_AFTER_K2 = 13, EDGE_INV_PENCIL_K1_AFTER_EX1 = 14 };
+#define PTAG(stage, idx) (((stage) << 16) | (idx)) /* pencil schedule: tag of a recorded step = (stage 1 K1/exchange 1 of tile idx, 2 K2/exchange 2
+                                                      of tile idx, 3 exchange 2 of the last tile's chunk idx, 4 K3 of chunk idx) */
 #ifdef OFFT_TEST_SEAMS
 static int edge_dropped(int id) {
   static int drop = -1;
@@ -2014,6 +2023,43 @@ static int p2p_barrier(hip_state *st, int which, void *stream) {
 static int execute_slab(struct _offt_plan *po, void *data);
 static int execute_pipeline(struct _offt_plan *po, void *data, int dir);
 
+/* one recorded step, mirrored, on `sx` */
+static int mirror_step(hip_state *st, const step_list *L, int i, void *sx) {
+  const offt_backend *be = st->be;
+  const step *e = &L->v[i];
+  if (e->kind == 0) {
+    offt_pass_desc d = e->d, f = e->d;
+    d.direction = +1;
+    d.in_axis_stride = f.out_axis_stride; d.in_col_stride = f.out_col_stride; d.in_b1_stride = f.out_b1_stride; d.in_b2_stride = f.out_b2_stride;
+    d.out_axis_stride = f.in_axis_stride; d.out_col_stride = f.in_col_stride; d.out_b1_stride = f.in_b1_stride; d.out_b2_stride = f.in_b2_stride;
+    d.in_split = f.out_split; d.in_split_nfloor = f.out_split_nfloor; d.in_block_stride = f.out_block_stride;
+    d.out_split = f.in_split; d.out_split_nfloor = f.in_split_nfloor; d.out_block_stride = f.in_block_stride;
+    d.in_block_tab = f.out_block_tab; d.out_block_tab = f.in_block_tab;
+    d.in_contig = f.out_contig; d.out_contig = f.in_contig;
+    d.scale = e->first ? st->out_scale : 1.0;
+    /* cache hint: forward, a pass with out_keep is followed by the pass that re-reads its output; mirrored, that
+     * follower is the producer and this one the consumer */
+    d.out_keep = (i > 0 && L->v[i - 1].kind == 0 && L->v[i - 1].d.out_keep && !f.out_keep) ? 1 : 0;
+    return be->pass(&d, e->dst, (void *)e->src, sx);
+  }
+  if (e->kind == 2)
+    /* one barrier per recorded flag operation, never merged: ranks with an empty tile record no pass between two
+     * operations where the others do, and every rank must run the same number of barriers */
+    return p2p_barrier(st, e->which, sx);
+  return be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, sx);
+}
+/* the steps recorded under `tag` that are exchanges (want_exchange) or passes, mirrored, last recorded first; returns how
+ * many ran, -1 on failure */
+static int mirror_tagged(hip_state *st, const step_list *L, int tag, int want_exchange, void *sx) {
+  int n = 0;
+  for (int i = L->n - 1; i >= 0; i--) {
+    if (L->v[i].tag != tag || (L->v[i].kind == 1) != (want_exchange != 0)) continue;
+    if (mirror_step(st, L, i, sx)) return -1;
+    n++;
+  }
+  return n;
+}
+
 static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   hip_state *st = (hip_state *)po->hip_state;
   const offt_backend *be = st->be;
@@ -2024,53 +2070,76 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   int rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, -1);
   st->rec = NULL;
   be->event_record(st->evp[0], s);
-  /* Slab schedule over the staged exchange: the mirror image keeps the forward's overlap.  Chunk by chunk, last chunk first:
-   * FFTx^-1 and FFTy^-1 of chunk h on the compute stream, then the chunk's exchange (send and receive sides swapped) on the
-   * comm stream while the next chunk's passes run; the FFTz^-1 launches wait for the last exchange -- what the forward
-   * transform exposes at its start (K1) the inverse exposes at its end.  Every other schedule replays in order on one stream. */
-  const int overlap = st->slab_zyx && st->x1 && !st->p2p && st->sH > 0 && st->ev_sa && st->ev_s1 && st->sNt > 0;
-  for (int pass = 0; pass < (overlap ? st->sH + 1 : 1) && !rc; pass++) {
-   const int want_tag = overlap ? (pass < st->sH ? st->sH - 1 - pass : -1) : 0; /* chunks H-1 .. 0, then the K1 phase */
-   int chunk_exchanged = 0;
-   if (overlap && want_tag < 0) SCHED_WAIT(EDGE_INV_K1_AFTER_EXCHANGES, s, st->ev_s1[0]); /* every exchange has landed */
-   for (int kind_turn = 0; kind_turn < (overlap ? 2 : 1) && !rc; kind_turn++) /* a chunk's passes first, then its exchanges */
-   for (int i = L.n - 1; i >= 0 && !rc; i--) {
-    step *e = &L.v[i];
-    void *sx = s;
-    if (overlap) {
-      if (e->tag != want_tag) continue;
-      if ((e->kind == 1) != (kind_turn == 1)) continue;
-      if (e->kind == 1) {
-        sx = st->s_comm1;
-        if (!chunk_exchanged) { be->event_record(st->ev_sa[want_tag], s); SCHED_WAIT(EDGE_INV_EXCHANGE_AFTER_PASSES, sx, st->ev_sa[want_tag]); chunk_exchanged = 1; }
+  const int overlap_slab = st->slab_zyx && st->x1 && !st->p2p && st->sH > 0 && st->ev_sa && st->ev_s1 && st->sNt > 0;
+  const int overlap_pencil = !st->slab_zyx && !st->p2p && (st->x1 || st->x2) && st->ntiles > 0 && st->ev_t2 && st->ev_a2 &&
+                             !(getenv("OFFT_INVERSE_IN_ORDER") && atoi(getenv("OFFT_INVERSE_IN_ORDER")));
+  if (rc) {
+  } else if (overlap_slab) {
+    /* Slab schedule over the staged exchange: the mirror image keeps the forward's overlap.  Chunk by chunk, last chunk first:
+     * FFTx^-1 and FFTy^-1 of chunk h on the compute stream, then the chunk's exchange (send and receive sides swapped) on the
+     * comm stream while the next chunk's passes run; the FFTz^-1 launches wait for the last exchange -- what the forward
+     * transform exposes at its start (K1) the inverse exposes at its end. */
+    for (int h = st->sH - 1; h >= 0 && rc >= 0; h--) {
+      rc = mirror_tagged(st, &L, h, 0, s);
+      if (rc < 0) break;
+      be->event_record(st->ev_sa[h], s);
+      SCHED_WAIT(EDGE_INV_EXCHANGE_AFTER_PASSES, st->s_comm1, st->ev_sa[h]);
+      rc = mirror_tagged(st, &L, h, 1, st->s_comm1);
+      be->event_record(st->ev_s1[0], st->s_comm1); /* (in order on the comm stream: the last record covers all) */
+    }
+    if (rc >= 0) {
+      SCHED_WAIT(EDGE_INV_K1_AFTER_EXCHANGES, s, st->ev_s1[0]); /* every exchange has landed */
+      rc = mirror_tagged(st, &L, -1, 0, s);
+    }
+    rc = rc < 0 ? -1 : 0;
+  } else if (overlap_pencil) {
+    /* Pencil schedule over the staged exchanges, mirrored with the forward's overlap:
+     *   K3'(h), h = H-1 .. 0, on the compute stream; behind each, the last x-tile's share of chunk h goes back over the
+     *     column group (exchange 2, sides swapped) on comm stream 2 -- under K3'(h-1) ..;
+     *   then the other tiles' exchange 2 (one message per peer holds every chunk of a tile, so it needs all K3'), tile by
+     *     tile, last tile first, with an event behind each;
+     *   K2'(k), k = last .. 0, as soon as its tile has landed; behind it exchange 1 of the tile (sides swapped) on comm
+     *     stream 1; K1'(k) W1 tiles later -- "K2'(k); K1'(k + W1)" on one in-order stream is the forward's software
+     *     pipeline run backwards, and the ring slot of tile k is free again when K2'(k - ring) is issued.             */
+    const int nt = st->ntiles, H = st->H2, W = st->ring - 1;
+    for (int g = H - 1; g >= 0 && rc >= 0; g--) {
+      rc = mirror_tagged(st, &L, PTAG(4, g), 0, s);
+      if (rc < 0 || !st->x2) continue;
+      be->event_record(st->ev_a2[g], s);
+      SCHED_WAIT(EDGE_INV_PENCIL_EX2_AFTER_K3, st->s_comm2, st->ev_a2[g]);
+      rc = mirror_tagged(st, &L, PTAG(3, g), 1, st->s_comm2);
+    }
+    for (int k = nt - 1; k >= 0 && rc >= 0 && st->x2; k--) {
+      if (k < nt - 1) rc = mirror_tagged(st, &L, PTAG(2, k), 1, st->s_comm2);
+      be->event_record(st->ev_t2[k], st->s_comm2);
+    }
+    be->event_record(st->evp[1], s);
+    be->event_record(st->evp[2], s);
+    for (int j = 0; j < nt + W && rc >= 0; j++) {
+      if (j < nt) {
+        const int k = nt - 1 - j, r = k % st->ring;
+        if (st->x2) SCHED_WAIT(EDGE_INV_PENCIL_K2_AFTER_EX2, s, st->ev_t2[k]);
+        rc = mirror_tagged(st, &L, PTAG(2, k), 0, s);
+        if (rc >= 0 && st->x1) {
+          be->event_record(st->ev_k2[r], s);
+          SCHED_WAIT(EDGE_INV_PENCIL_EX1_AFTER_K2, st->s_comm1, st->ev_k2[r]);
+          rc = mirror_tagged(st, &L, PTAG(1, k), 1, st->s_comm1);
+          be->event_record(st->ev_a1[r], st->s_comm1);
+        }
+      }
+      const int jj = j - W;
+      if (jj >= 0 && jj < nt && rc >= 0) {
+        const int k = nt - 1 - jj, r = k % st->ring;
+        if (st->x1) SCHED_WAIT(EDGE_INV_PENCIL_K1_AFTER_EX1, s, st->ev_a1[r]);
+        rc = mirror_tagged(st, &L, PTAG(1, k), 0, s);
       }
     }
-    if (e->kind == 0) {
-      offt_pass_desc d = e->d, f = e->d;
-      d.direction = +1;
-      d.in_axis_stride = f.out_axis_stride; d.in_col_stride = f.out_col_stride; d.in_b1_stride = f.out_b1_stride; d.in_b2_stride = f.out_b2_stride;
-      d.out_axis_stride = f.in_axis_stride; d.out_col_stride = f.in_col_stride; d.out_b1_stride = f.in_b1_stride; d.out_b2_stride = f.in_b2_stride;
-      d.in_split = f.out_split; d.in_split_nfloor = f.out_split_nfloor; d.in_block_stride = f.out_block_stride;
-      d.out_split = f.in_split; d.out_split_nfloor = f.in_split_nfloor; d.out_block_stride = f.in_block_stride;
-      d.in_block_tab = f.out_block_tab; d.out_block_tab = f.in_block_tab;
-      d.in_contig = f.out_contig; d.out_contig = f.in_contig;
-      d.scale = e->first ? st->out_scale : 1.0;
-      /* cache hint: forward, a pass with out_keep is followed by the pass that re-reads its output; mirrored, that
-       * follower is the producer and this one the consumer */
-      d.out_keep = (i > 0 && L.v[i - 1].kind == 0 && L.v[i - 1].d.out_keep && !f.out_keep) ? 1 : 0;
-      rc = be->pass(&d, e->dst, (void *)e->src, sx);
-    } else if (e->kind == 2) {
-      /* one barrier per recorded flag operation, never merged: ranks with an empty tile record no pass between two
-       * operations where the others do, and every rank must run the same number of barriers */
-      rc = p2p_barrier(st, e->which, sx);
-    } else {
-      rc = be->a2a(st, e->which, e->cnt, e->peer, (const void *const *)e->rp, e->rb, (void *const *)e->sp, e->sb, sx);
-    }
-   }
-   if (overlap && chunk_exchanged) be->event_record(st->ev_s1[0], st->s_comm1); /* (in order on the comm stream: the last record covers all) */
+    rc = rc < 0 ? -1 : 0;
+  } else {
+    /* every other schedule (direct-store exchange: barriers) replays in order on the compute stream */
+    for (int i = L.n - 1; i >= 0 && !rc; i--) rc = mirror_step(st, &L, i, s);
   }
-  be->event_record(st->evp[1], s);
-  be->event_record(st->evp[2], s);
+  if (!overlap_pencil) { be->event_record(st->evp[1], s); be->event_record(st->evp[2], s); }
   be->event_record(st->evp[3], s);
   rec_free(&L);
   return rc;
@@ -2378,6 +2447,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- K1(i): FFTz + pack1 (offt-compute.c:905-1206) ---- */
       const int r = i % st->ring, x0 = i * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
+      st->rec_tag = PTAG(1, i);
       if (i >= st->ring) be->stream_wait(s, st->ev_k2[r]); /* slot's previous tile fully consumed */
       if (pp1) { /* ... by every row peer: they read what this rank stored into THEIR slot r */
         if (run_wait(st, &st->g1, st->ring + r, st->use1[r], s, EDGE_P2P_WAIT_FREE)) return -1;
@@ -2429,6 +2499,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
       /* ---- K2(k): unpack1 + FFTy (+ pack2) (offt-compute.c:1208-1520, 1636-2345) ---- */
       const int r = k % st->ring, x0 = k * T;
       int myT = c->m1 - x0; if (myT > T) myT = T; if (myT < 0) myT = 0;
+      st->rec_tag = PTAG(2, k);
       if (pp1) { if (run_wait(st, &st->g1, r, st->use1[r], s, EDGE_P2P_WAIT_READY)) return -1; }
       else if (st->x1) SCHED_WAIT(EDGE_PENCIL_K2_AFTER_EX1, s, st->ev_a1[r]);
       if (pp2 && k == 0 && run_wait(st, &st->g2, 1, ep - 1, s, EDGE_P2P_WAIT_FREE)) return -1; /* the column peers have consumed the previous transform's recv2 */
@@ -2515,6 +2586,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
               any |= (sb[e] || rb[e]);
             }
           }
+          st->rec_tag = last ? PTAG(3, g) : PTAG(2, k);
           if (any && run_a2a(st, 2, cnt, pr, sp, sb, rp, rb, st->s_comm2)) return -1;
           if (last) be->event_record(st->ev_a2[g], st->s_comm2);
         }
@@ -2529,6 +2601,7 @@ static int execute_pipeline(struct _offt_plan *po, void *data, int dir) {
     int tzh = c->M3 - z0; if (tzh > Tz) tzh = Tz;
     int nz = c->m3 - z0; if (nz > tzh) nz = tzh;
     if (st->x2 && !pp2) SCHED_WAIT(EDGE_PENCIL_K3_AFTER_EX2, s, st->ev_a2[w2 == 0 ? H - 1 : h]);
+    st->rec_tag = PTAG(4, h);
     if (nz <= 0 || c->m4 <= 0) continue;
     offt_pass_desc d;
     desc_init(&d, st, Nx, dir, 0);

@@ -52,7 +52,12 @@ def run_world(size, cases, tmp_path):
 
 
 def run_thread_world(size, cases, tmp_path, env=None):
-    """`size` ranks as threads of ONE process on the one GPU (the box admits at most 6 processes on the card)"""
+    """`size` ranks as threads of ONE process on the one GPU (the box admits at most 6 processes on the card).
+    GPU_MAX_HW_QUEUES: HIP maps a process's streams onto a few hardware queues (4 by default) and two streams sharing one run
+    in order -- a missing event edge between them would then go unnoticed, depending on which streams happened to land
+    together (tools/async_negative_control.sh caught edges 2 and 5 in one run and not in the next until the queues were
+    raised above the number of streams)."""
+    env = dict({"GPU_MAX_HW_QUEUES": "24"}, **(env or {}))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_thread_world.py"), str(size), json.dumps(cases), str(tmp_path)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout.decode()[-4000:]
@@ -214,12 +219,15 @@ def test_staged_exchange_with_an_asynchronous_transport(built, tmp_path):
     run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1), repeat=2, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=2), repeat=2, **{"async": 1}),
                          dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=8), inv=1, repeat=1, **{"async": 1}),
                          dict(N=[256, 128, 256], params=dict(P1=2, T1=16, W1=1, T2=16), inv=1, repeat=1, **{"async": 1}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, S=1, T1=16, W1=1, T2=16), inv=1, repeat=1, **{"async": 1}),
                          dict(N=[256, 256, 256], params=dict(P1=1, S=1), repeat=1, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=1), f32=1, repeat=1, **{"async": 1})], tmp_path)
     # the other half: a FAST wire ("async": 2) and SLOW passes (the test build holds the stream 50 ms ahead of every pass), so
     # that the host runs far ahead of the device and an exchange that did not wait for the kernel packing its data would
-    # read too early.  All eight numbered edges of offt_host.c, dropped one at a time, come out wrong in these worlds:
+    # read too early.  All numbered edges of offt_host.c (forward and mirrored schedules), dropped one at a time, come out wrong in these worlds:
     # profiles/r03_async_negative_control.txt
     run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1, T1=64, T2=32), repeat=1, **{"async": 2}),
                          dict(N=[256, 256, 256], params=dict(P1=1, T1=64, T2=32), inv=1, **{"async": 2}),
-                         dict(N=[256, 256, 256], params=dict(P1=2, T1=32, W1=1, T2=32), repeat=1, **{"async": 2})], tmp_path,
+                         dict(N=[256, 256, 256], params=dict(P1=2, T1=32, W1=1, T2=32), repeat=1, **{"async": 2}),
+                         dict(N=[256, 256, 256], params=dict(P1=2, T1=32, W1=1, T2=32), inv=1, **{"async": 2}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, S=1, T1=32, W1=1, T2=32), inv=1, **{"async": 2})], tmp_path,
                      env=dict(OFFT_TEST_SLOW_PASS_MS="50"))
