@@ -272,6 +272,15 @@ def rank_main(args):
     import ctypes as C
     import faulthandler
     faulthandler.dump_traceback_later(args.launch_timeout, exit=True)  # a stuck rank ends with a traceback, not silently
+    # stdout carries ONE line, the JSON record: the library prints its plan parameters there at init, as the reference does
+    # (offt-compute.c:3416) -- they go to stderr for the length of this run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    # HIP maps a process's streams onto 4 hardware queues by default and two streams on one queue run in order: a plan's
+    # compute and comm streams must not end up sharing one (the exchange would no longer run under the passes).  Read by the
+    # HIP runtime when it starts, hence before torch is imported; no effect on one GPU (16.94 against 16.96 ms)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     from offt_amd import api
@@ -520,7 +529,8 @@ def rank_main(args):
                 out["cpu_baseline"]["sample"] += f" (host MemAvailable {mem_available_gib():.0f} GiB)"
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         api.lib().offt_hip_finalize_world()
