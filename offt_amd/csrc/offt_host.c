@@ -1144,10 +1144,6 @@ struct _offt_plan *offt_3d_init_ex(int Nx, int Ny, int Nz, void *in, void *out, 
     if (!g_backend) SET_ERR("no kernel for this grid: %s", offt_hipk_last_error());
     goto fail;
   }
-  if (!g_backend && is_r2c && offt_hipk_is_four_step(Nz, precision)) {
-    SET_ERR("offt_3d_init: real-to-complex lines of %d points are not supported (lines this long run as a four-step decomposition, complex input only)", Nz);
-    goto fail;
-  }
   st->s_compute = be->stream_create(); st->own_stream = 1;
   st->ev0 = be->event_create(); st->ev1 = be->event_create();
   for (int i = 0; i < 4; i++) st->evp[i] = be->event_create();

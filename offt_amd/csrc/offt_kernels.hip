@@ -831,7 +831,7 @@ int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 struct FourStep { int n1 = 0, n2 = 0; };
 std::mutex g_four_mu;
 std::map<std::pair<int, int>, FourStep> g_four;
-struct Scratch { void *p[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
+struct Scratch { void *p[3] = {nullptr, nullptr, nullptr}; size_t bytes[3] = {0, 0, 0}; };  // 0, 1: four-step; 2: lines through scratch
 std::map<void *, Scratch> g_four_scratch;  // per stream
 
 bool four_lookup(int n, int prec, FourStep *out) {
@@ -904,6 +904,82 @@ __global__ void __launch_bounds__(256) four_twiddle_t_k(const V2 *sp, V2 *s, con
 }
 
 int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const FourStep &fs);
+// ---------------------------------------------------------------------------
+// Lines through a dense scratch: the last net under "FFTW plans any length".
+//   * a line no single launch takes and no four-step split fits (a prime beyond the any-length kernel, or a prime factor
+//     too large itself) runs as a Bluestein convolution on M-point lines, M the power of two >= 2n - 1:
+//       gather x[j] a[j] into U[line][0..M) (zero padded) | FFT_M | times B^ | FFT_M^-1 | scatter a[k] U[line][k], k < n
+//     with the library's own M-point path (a panel kernel or the four-step decomposition) on contiguous lines;
+//   * a real-input line too long for the r2c kernels is gathered as complex, transformed by the complex path of the same
+//     length, and its first n/2 + 1 outputs scattered.
+// Seven (three) sweeps over scratch lines of twice the length: a few per cent of the roofline -- it exists so that no
+// grid the reference accepts is refused, not to be fast.
+// ---------------------------------------------------------------------------
+struct LongTab { void *chirp = nullptr, *bhat = nullptr; int m = 0; };
+std::map<std::pair<int, int>, LongTab> g_long;  // (guarded by g_blue_mu)
+bool long_lookup(int n, int prec, LongTab *out) {
+  std::lock_guard<std::mutex> lk(g_blue_mu);
+  auto it = g_long.find(std::make_pair(n, prec));
+  if (it == g_long.end()) return false;
+  if (out) *out = it->second;
+  return true;
+}
+
+// U[l][j] = x_line(line0 + l)[j] (* chirp[j]), j < n; 0 for n <= j < m.  Lines are numbered (b2, b1, column), column fastest
+template <typename T>
+__global__ void __launch_bounds__(256)
+long_gather_k(GenArgs a, const typename vec2<T>::type *in, typename vec2<T>::type *U, const typename vec2<T>::type *chirp, int m,
+              long long line0, long long total) {
+  using V2 = typename vec2<T>::type;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % m);
+  const long long L = line0 + i / m;
+  const int c = (int)(L % a.ncols);
+  const long long r = L / a.ncols;
+  const int b1 = (int)(r % a.nb1), b2 = (int)(r / a.nb1);
+  V2 x; x.x = 0; x.y = 0;
+  if (j < a.n) {
+    const V2 *src = in + (long long)b1 * a.in_b1 + (long long)b2 * a.in_b2 + (long long)c * a.in_col;
+    if (a.real_in) x.x = reinterpret_cast<const T *>(src)[j];
+    else x = src[split_off(j, a.in_split, a.in_nfloor, a.in_blk, a.in_axis, a.in_tab)];
+    if (a.conj) x.y = -x.y;
+    if (chirp) { const V2 w = chirp[j]; V2 t; t.x = x.x * w.x - x.y * w.y; t.y = x.x * w.y + x.y * w.x; x = t; }
+  }
+  U[i] = x;
+}
+// U[l][k] *= bhat[k]
+template <typename V2>
+__global__ void __launch_bounds__(256) long_mul_k(V2 *U, const V2 *bhat, int m, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const V2 w = bhat[(int)(i % m)], x = U[i];
+  V2 t; t.x = x.x * w.x - x.y * w.y; t.y = x.x * w.y + x.y * w.x;
+  U[i] = t;
+}
+// out_line(line0 + l)[k] = U[l][k] (* chirp[k]) * scale, k < kend
+template <typename T>
+__global__ void __launch_bounds__(256)
+long_scatter_k(GenArgs a, const typename vec2<T>::type *U, typename vec2<T>::type *out, const typename vec2<T>::type *chirp, int m, int kend,
+               long long line0, long long total) {
+  using V2 = typename vec2<T>::type;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % kend);
+  const long long l = i / kend, L = line0 + l;
+  const int c = (int)(L % a.ncols);
+  const long long r = L / a.ncols;
+  const int b1 = (int)(r % a.nb1), b2 = (int)(r / a.nb1);
+  V2 x = U[l * m + k];
+  if (chirp) { const V2 w = chirp[k]; V2 t; t.x = x.x * w.x - x.y * w.y; t.y = x.x * w.y + x.y * w.x; x = t; }
+  V2 o;
+  o.x = x.x * (T)a.scale;
+  o.y = (a.conj ? -x.y : x.y) * (T)a.scale;
+  V2 *dst = out + (long long)b1 * a.out_b1 + (long long)b2 * a.out_b2 + (long long)c * a.out_col;
+  dst[split_off(k, a.out_split, a.out_nfloor, a.out_blk, a.out_axis, a.out_tab)] = o;
+}
+
+int long_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const LongTab &lt);
 
 }  // namespace
 
@@ -1000,7 +1076,18 @@ int offt_hipk_prepare(int n, int precision) {
       g_four[std::make_pair(n, precision)] = fs;
     }
   }
-  if (no_direct && !four_lookup(n, precision, nullptr)) {
+  // ... and a length without a split becomes a Bluestein convolution on lines of M = 2^k >= 2n - 1 points through scratch
+  static const bool long_on = !(getenv("OFFT_BLUESTEIN_LONG") && atoi(getenv("OFFT_BLUESTEIN_LONG")) == 0);
+  if (no_direct && !four_lookup(n, precision, nullptr) && long_on && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
+    BlueTab bt;
+    const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
+    if (!rc) {
+      std::lock_guard<std::mutex> lk(g_blue_mu);
+      LongTab lt; lt.chirp = bt.chirp; lt.bhat = bt.bhat; lt.m = bt.m;
+      g_long[std::make_pair(n, precision)] = lt;
+    }
+  }
+  if (no_direct && !four_lookup(n, precision, nullptr) && !long_lookup(n, precision, nullptr)) {
     snprintf(g_err, sizeof g_err, "no kernel for lines of %d %s points: no register kernel, the any-length kernel holds at most %zu, and %d has no "
              "factorisation n1 n2 into lengths that have one", n, precision == OFFT_PREC_F64 ? "double-complex" : "single-complex",
              (size_t)160 * 1024 / (2 * esz), n);
@@ -1025,6 +1112,8 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
       const bool no_direct = !find_variant(d->n, d->precision, true, true, -1) && 2 * (size_t)d->n * esz4 > (size_t)160 * 1024;
       if (no_direct || !(d->in_contig && d->out_contig)) return four_pass(d, in, out, stream, fs);
     }
+    LongTab lt;
+    if (long_lookup(d->n, d->precision, &lt)) return long_pass(d, in, out, stream, lt);
   }
   Variant *v = pick_variant(d);
   if (v && v->prec == OFFT_PREC_F32_PAIR &&
@@ -1168,12 +1257,12 @@ namespace {
 int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const FourStep &fs) {
   const int N = d->n, N1 = fs.n1, N2 = fs.n2;
   const size_t esz = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
-  if (d->real_input) { snprintf(g_err, sizeof g_err, "four-step path: real-input lines of %d points are not supported", N); return -1; }
-  // a per-peer split must cut the axis where the decomposition can follow it: whole runs of n2 inputs / n1 outputs
+  if (d->real_input) { LongTab plain; return long_pass(d, in, out, stream, plain); }  // gathered as complex lines, first n/2 + 1 outputs scattered
+  // a per-peer split must cut the axis where the decomposition can follow it: whole runs of n2 inputs / n1 outputs.  One that
+  // does not (uneven blocks) sends the lines through scratch: gathered with the split, transformed as contiguous lines
   if ((d->in_split && (d->in_split_nfloor || d->in_split % N2)) || (d->out_split && (d->out_split_nfloor || d->out_split % N1))) {
-    snprintf(g_err, sizeof g_err, "four-step path (%d = %d x %d): per-peer blocks of %d / %d points do not fit the decomposition", N, N1, N2,
-             d->in_split, d->out_split);
-    return -1;
+    LongTab plain;
+    return long_pass(d, in, out, stream, plain);
   }
   Tables tb;
   if (get_tables(N, d->precision, tb, false)) return -1;
@@ -1264,6 +1353,68 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
         }
         if (offt_hipk_fft_pass(&c, S, pout, stream)) return -1;
       }
+  return 0;
+}
+
+int long_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, const LongTab &lt) {
+  const int N = d->n, M = lt.m ? lt.m : N;   // (lt.m == 0: plain complex lines of N points, the long real-input case)
+  const size_t esz = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
+  const hipStream_t st = (hipStream_t)stream;
+  GenArgs g;
+  memset(&g, 0, sizeof g);
+  g.in_axis = d->in_axis_stride; g.in_col = d->in_col_stride; g.in_b1 = d->in_b1_stride; g.in_b2 = d->in_b2_stride;
+  g.out_axis = d->out_axis_stride; g.out_col = d->out_col_stride; g.out_b1 = d->out_b1_stride; g.out_b2 = d->out_b2_stride;
+  g.in_blk = d->in_block_stride; g.out_blk = d->out_block_stride;
+  g.in_split = d->in_split; g.in_nfloor = d->in_split_nfloor;
+  g.out_split = d->out_split; g.out_nfloor = d->out_split_nfloor;
+  g.n = N; g.ncols = d->ncols; g.nb1 = d->nb1;
+  g.conj = d->direction > 0;
+  g.real_in = d->real_input;
+  g.scale = d->scale;
+  g.in_tab = d->in_split ? d->in_block_tab : nullptr;
+  g.out_tab = d->out_split ? d->out_block_tab : nullptr;
+  const int kend = d->real_input ? N / 2 + 1 : N;
+  const long long nlines = (long long)d->ncols * d->nb1 * d->nb2;
+  long long per = (long long)(((size_t)256 << 20) / ((size_t)M * esz));
+  if (per < 1) per = 1;
+  if (per > nlines) per = nlines;
+  char *U = (char *)four_scratch(stream, 2, (size_t)per * M * esz);
+  if (!U) { snprintf(g_err, sizeof g_err, "lines of %d points through scratch: cannot allocate %zu bytes", N, (size_t)per * M * esz); return -1; }
+  // the M-point transforms of the scratch lines: contiguous lines, in place
+  offt_pass_desc f;
+  memset(&f, 0, sizeof f);
+  f.n = M; f.precision = d->precision; f.variant = -1; f.scale = 1.0; f.no_pairs = d->no_pairs;
+  f.in_axis_stride = f.out_axis_stride = 1; f.in_contig = f.out_contig = 1;
+  f.in_col_stride = f.out_col_stride = M; f.nb1 = f.nb2 = 1;
+  for (long long l0 = 0; l0 < nlines; l0 += per) {
+    const long long nl = nlines - l0 < per ? nlines - l0 : per;
+    const long long tot = nl * M, tote = nl * kend;
+    if (tot > 0x7fffffffLL * 256) { snprintf(g_err, sizeof g_err, "lines of %d points through scratch: chunk too large", N); return -1; }
+    const unsigned blocks = (unsigned)((tot + 255) / 256), blockse = (unsigned)((tote + 255) / 256);
+    f.ncols = (int)nl;
+    (void)hipGetLastError();
+    if (d->precision == OFFT_PREC_F64)
+      hipLaunchKernelGGL(long_gather_k<double>, dim3(blocks), dim3(256), 0, st, g, (const double2 *)in, (double2 *)U, (const double2 *)lt.chirp, M, l0, tot);
+    else
+      hipLaunchKernelGGL(long_gather_k<float>, dim3(blocks), dim3(256), 0, st, g, (const float2 *)in, (float2 *)U, (const float2 *)lt.chirp, M, l0, tot);
+    HIPK_CHECK(hipGetLastError());
+    f.direction = -1;
+    if (offt_hipk_fft_pass(&f, U, U, stream)) return -1;
+    if (lt.m) {
+      if (d->precision == OFFT_PREC_F64)
+        hipLaunchKernelGGL(long_mul_k<double2>, dim3(blocks), dim3(256), 0, st, (double2 *)U, (const double2 *)lt.bhat, M, tot);
+      else
+        hipLaunchKernelGGL(long_mul_k<float2>, dim3(blocks), dim3(256), 0, st, (float2 *)U, (const float2 *)lt.bhat, M, tot);
+      HIPK_CHECK(hipGetLastError());
+      f.direction = +1;
+      if (offt_hipk_fft_pass(&f, U, U, stream)) return -1;
+    }
+    if (d->precision == OFFT_PREC_F64)
+      hipLaunchKernelGGL(long_scatter_k<double>, dim3(blockse), dim3(256), 0, st, g, (const double2 *)U, (double2 *)out, (const double2 *)lt.chirp, M, kend, l0, tote);
+    else
+      hipLaunchKernelGGL(long_scatter_k<float>, dim3(blockse), dim3(256), 0, st, g, (const float2 *)U, (float2 *)out, (const float2 *)lt.chirp, M, kend, l0, tote);
+    HIPK_CHECK(hipGetLastError());
+  }
   return 0;
 }
 }  // namespace

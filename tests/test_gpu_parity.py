@@ -6,6 +6,7 @@ single rel-L2 <= 5e-6."""
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -15,6 +16,8 @@ import torch
 import oracle_lib as O
 from gpu_util import gpu_fft, make_input, read_output, rel, gpu_roundtrip
 from offt_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -415,14 +418,30 @@ def test_long_lines_four_step(built, shape, prec, kw):
     assert back < (TOL64 if prec == api.F64 else TOL32)
 
 
+@pytest.mark.parametrize("shape,prec,r2c,kw", [((8, 8, 10007), api.F64, 0, {}), ((4, 20011, 4), api.F32, 0, {}), ((10007, 4, 4), api.F64, 0, dict(S=1)),
+                                               ((8, 8, 6000), api.F64, 1, {}), ((4, 4, 16384), api.F32, 1, {}), ((4, 4, 10007), api.F64, 1, {})])
+def test_long_lines_through_scratch(built, shape, prec, r2c, kw):
+    """what the four-step decomposition leaves: a long PRIME line (no n1 n2 to decompose along) runs as a Bluestein
+    convolution on power-of-two lines of >= 2n - 1 points, a long real-input line as a complex line whose first n/2 + 1
+    outputs are kept -- both through dense scratch lines with the library's own long-line path.  Against numpy (the oracle's
+    prime lines are plain O(n^2) sums); complex: inverse round trip as well."""
+    f = O.hash_field(*shape)
+    got, _ = gpu_fft(shape, field=f, precision=prec, is_r2c=r2c, **kw)
+    want = np.fft.rfftn(f.real) if r2c else np.fft.fftn(f)
+    assert rel(got, want) < (TOL64 if prec == api.F64 else TOL32), (shape, kw)
+    if not r2c:
+        assert gpu_roundtrip(shape, precision=prec, **kw) < (TOL64 if prec == api.F64 else TOL32)
+
+
 def test_lengths_without_any_kernel_are_refused_at_plan_time(built):
-    """what is left: a long PRIME line (no factorisation n1 n2 to decompose along) and long real-input lines must fail in
-    offt_3d_init, not on every execute"""
-    for shape, prec, r2c in (((8, 8, 10007), api.F64, 0), ((4, 20011, 4), api.F32, 0), ((8, 8, 6000), api.F64, 1)):
-        with pytest.raises(RuntimeError, match="offt_3d_init failed"):
-            api.offt_3d_init(*shape, precision=prec, is_r2c=r2c)
-    po = api.offt_3d_init(8, 8, 5000)   # 5000 = 2^3 5^4 fits the any-length kernel
-    api.offt_3d_fin(po)
+    """with the Bluestein net switched off (OFFT_BLUESTEIN_LONG=0) a long prime line has no kernel: that must fail in
+    offt_3d_init, not on every execute (the switch is read once per process, hence a process of its own)"""
+    code = ("import sys; sys.path[:0] = [%r, %r]\nfrom offt_amd import api\n"
+            "try:\n    api.offt_3d_init(8, 8, 10007)\nexcept RuntimeError as e:\n    assert 'offt_3d_init failed' in str(e), e; print('REFUSED')\n"
+            "po = api.offt_3d_init(8, 8, 5000); api.offt_3d_fin(po); print('OK5000')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OFFT_BLUESTEIN_LONG="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "REFUSED" in out and "OK5000" in out, out   # (5000 = 2^3 5^4 fits the any-length kernel)
 
 
 def test_linearity_and_shift(built):
@@ -632,6 +651,6 @@ def test_harness_and_static_sweep(built, tmp_path):
                                     "-L", "64", "-v"], stderr=subprocess.STDOUT, timeout=300).decode()
     assert any(l.startswith("p 0: 0 0 0: ") for l in out3.splitlines()), out3
     # a run the library cannot do must FAIL: non-zero exit and the reference's t_min 999999999 line, not timings of
-    # an untransformed buffer (10007 points, a prime: no kernel takes the line and there is no n1 n2 to decompose along)
-    p = subprocess.run([exe, "-N", "10007", "-n", "4", "-L", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # an untransformed buffer (10007 points, a prime, with the Bluestein net under the four-step path switched off: no kernel)
+    p = subprocess.run([exe, "-N", "10007", "-n", "4", "-L", "4"], env=dict(env, OFFT_BLUESTEIN_LONG="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode != 0 and "t_min 999999999" in p.stdout.decode(), p.stdout.decode()

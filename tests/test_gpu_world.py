@@ -197,6 +197,15 @@ def test_direct_store_exchange_between_processes_hipipc(built, tmp_path):
     run_world(4, [dict(N=[64, 64, 64], params=dict(P1=2), p2p=1, repeat=1), dict(N=[128, 128, 128], params=dict(P1=1), p2p=1)], tmp_path)
 
 
+def test_long_lines_in_worlds(built, tmp_path):
+    """lines beyond the single-launch kernels on three ranks: a long prime (Bluestein through scratch) on the z axis of the
+    slab schedule and on the y axis of a 3 x 1 pencil mesh -- the per-peer blocks of 10007 points are uneven --, a four-step
+    length whose uneven per-peer blocks the decomposition cannot follow (6250 over 3: through scratch as well), a long
+    real-input line; forward against numpy and the oracle, mirrored inverse"""
+    run_thread_world(3, [dict(N=[4, 6, 10007], params=dict(P1=1), inv=1), dict(N=[6, 10007, 4], params=dict(P1=3)),
+                         dict(N=[4, 6, 6250], params=dict(P1=1), inv=1), dict(N=[6, 4, 12000], params=dict(P1=1), r2c=1)], tmp_path)
+
+
 def test_staged_exchange_with_an_asynchronous_transport(built, tmp_path):
     """The staged (default) exchange with NOTHING drained on the host: the test transport enqueues device-to-device copies
     on the ranks' comm streams, ordered between ranks by events only (tests/_thread_world.py, "async"), so the schedules'
