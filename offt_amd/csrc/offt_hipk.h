@@ -61,10 +61,13 @@ typedef struct offt_pass_desc {
   /* single precision: 1 = do not use the column-pair kernels for this pass (plan option OFFT_HIP_OPT_F32_PAIRS) */
   int no_pairs;
   /* first sub-pass of a four-step line (set by the launcher itself, offt_kernels.hip): multiply output index k1 of column
-   * j2 (tw4_b1 = 0) or of batch entry b1 = j2 (tw4_b1 = 1) by tw4[k1 * j2], tw4 = the exact full-wave table of the long
-   * length.  NULL otherwise.  Needs a kernel with the twiddles on its stores (strided / strided, 32 ... 256 points). */
+   * j2 (tw4_b1 = 0) or of batch entry b1 = j2 (tw4_b1 = 1) by tw4[k1 * tw4_n2 + j2] = w_n^(k1 j2), a table of the long
+   * length n = n1 n2 laid out [k1][j2] (the lanes of a wave are neighbouring columns j2: one 128-B line per 8 lanes, where
+   * indexing the full-wave table by k1 j2 would touch a line per lane).  NULL otherwise.  Needs a kernel with the twiddles
+   * on its stores (strided / strided, 32 ... 256 points). */
   const void *tw4;
   int tw4_b1;
+  int tw4_n2;
 } offt_pass_desc;
 
 /* Build device twiddle tables etc. for length n; call at plan time (allocates). */

@@ -828,7 +828,7 @@ int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 // stays a 128-B segment.  For a strided-in pass step A writes S'[k1][j2][column] and T transposes on the way.
 // Three sweeps over the data instead of one: a correctness net with decent bandwidth, not a tuned path.
 // ---------------------------------------------------------------------------
-struct FourStep { int n1 = 0, n2 = 0; };
+struct FourStep { int n1 = 0, n2 = 0; void *t4 = nullptr; };  // t4[k1][j2] = w_n^(k1 j2), from the exact full-wave table
 std::mutex g_four_mu;
 std::map<std::pair<int, int>, FourStep> g_four;
 struct Scratch { void *p[3] = {nullptr, nullptr, nullptr}; size_t bytes[3] = {0, 0, 0}; };  // 0, 1: four-step; 2: lines through scratch
@@ -863,6 +863,12 @@ void *four_scratch(void *stream, int which, size_t bytes) {
   return sc.p[which];
 }
 
+// t4[k1][j2] = tw[k1 j2] (k1 j2 < n)
+template <typename V2>
+__global__ void __launch_bounds__(256) four_table_k(V2 *t4, const V2 *tw, int n, int n2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) t4[i] = tw[(long long)(i / n2) * (i % n2)];
+}
 // T, in place: S[q][k1][j2] *= w_n^(+-(k1 j2))
 template <typename V2>
 __global__ void __launch_bounds__(256) four_twiddle_k(V2 *s, const V2 *tw, long long total, int n1, int n2, int conj) {
@@ -1065,14 +1071,27 @@ int offt_hipk_prepare(int n, int precision) {
       double score = std::log((double)n2 / (double)n1);
       if (!f1) score += 4.0;
       if (!f2) score += 4.0;
+      // ... except that a SHORT first sub-pass wins when the other factor still has a register kernel: 32 points in single,
+      // 64 in double precision -- few points per line, 64 (8) unit-stride columns per workgroup and the twiddles on its stores.
+      // Swept over 8192 / 16384 / 32768 points (profiles/r03_four_step.txt): single precision 8192 = 32 x 256 at 37.5 % of
+      // the roofline against 31.9 % (64 x 128) and 28.8 % (128 x 64); double 64 x 128 at 37.3 % against 36.4 % (32 x 256)
+      const int pref = precision == OFFT_PREC_F64 ? 64 : 32;
+      if ((n1 == pref || (n1 == 32 && n % pref)) && f2 && find_variant(n1, precision, false, false, -1, false, false, true)) score = n1 == pref ? -2.0 : -1.0;
       if (score < best_score) { best_score = score; best1 = n1; }
     }
+    if (getenv("OFFT_FOURSTEP_N1") && atoi(getenv("OFFT_FOURSTEP_N1")) > 1 && n % atoi(getenv("OFFT_FOURSTEP_N1")) == 0) best1 = atoi(getenv("OFFT_FOURSTEP_N1"));
     if (best1 && (offt_hipk_prepare(best1, precision) || offt_hipk_prepare(n / best1, precision) ||
                   !direct_ok(best1, precision) || !direct_ok(n / best1, precision)))
       best1 = 0;
     if (best1) {
-      std::lock_guard<std::mutex> lk(g_four_mu);
       FourStep fs; fs.n1 = best1; fs.n2 = n / best1;
+      HIPK_CHECK(hipMalloc(&fs.t4, (size_t)n * esz));
+      (void)hipGetLastError();
+      if (precision == OFFT_PREC_F64) hipLaunchKernelGGL(four_table_k<double2>, dim3((n + 255) / 256), dim3(256), 0, nullptr, (double2 *)fs.t4, (const double2 *)tb.full, n, fs.n2);
+      else hipLaunchKernelGGL(four_table_k<float2>, dim3((n + 255) / 256), dim3(256), 0, nullptr, (float2 *)fs.t4, (const float2 *)tb.full, n, fs.n2);
+      HIPK_CHECK(hipGetLastError());
+      HIPK_CHECK(hipStreamSynchronize(nullptr));
+      std::lock_guard<std::mutex> lk(g_four_mu);
       g_four[std::make_pair(n, precision)] = fs;
     }
   }
@@ -1145,7 +1164,7 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     a.scale = d->scale;
     a.in_tab = d->in_split ? d->in_block_tab : nullptr;
     a.out_tab = d->out_split ? d->out_block_tab : nullptr;
-    a.tw4 = d->tw4; a.tw4_b1 = d->tw4_b1;
+    a.tw4 = d->tw4; a.tw4_b1 = d->tw4_b1; a.tw4_n2 = d->tw4_n2;
     if (d->tw4 && !(v && v->tw4)) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: no kernel with four-step twiddles for n=%d", d->n); return -1; }
     long long nblk = (long long)a.ncp * d->nb1 * d->nb2;
     if (nblk > 0x7fffffffLL) { snprintf(g_err, sizeof g_err, "offt_hipk_fft_pass: grid too large"); return -1; }
@@ -1268,7 +1287,8 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
   if (get_tables(N, d->precision, tb, false)) return -1;
   const bool inL = d->in_contig != 0, outL = d->out_contig != 0;
   // columns per chunk: whole rows of the caller's column dimension, as many b1 entries as fit 256 MiB of scratch
-  const size_t cap = ((size_t)256 << 20) / esz;
+  static const int chunk_mib = getenv("OFFT_FOURSTEP_CHUNK_MIB") && atoi(getenv("OFFT_FOURSTEP_CHUNK_MIB")) > 0 ? atoi(getenv("OFFT_FOURSTEP_CHUNK_MIB")) : 192;
+  const size_t cap = ((size_t)chunk_mib << 20) / esz;
   int cc = d->ncols, cb1 = d->nb1;
   if ((size_t)cc * N > cap) { cc = (int)(cap / N); if (cc < 1) cc = 1; cb1 = 1; }
   else { const size_t fit = cap / ((size_t)cc * N); if ((size_t)cb1 > fit) cb1 = (int)(fit < 1 ? 1 : fit); }
@@ -1295,7 +1315,7 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
         static const bool fuse_on = !(getenv("OFFT_FOURSTEP_FUSE") && atoi(getenv("OFFT_FOURSTEP_FUSE")) == 0);
         const bool fused = fuse_on && (inL || !outL) && (!d->in_split || is_pow2(d->in_split / N2)) &&
                            find_variant(N1, d->precision, false, false, -1, false, false, true) != nullptr;
-        if (fused) { a.tw4 = tb.full; a.tw4_b1 = inL ? 0 : 1; }
+        if (fused) { a.tw4 = fs.t4; a.tw4_b1 = inL ? 0 : 1; a.tw4_n2 = N2; }
         if (inL) {  // the axis is the unit-stride dimension: j2 becomes the column dimension
           a.ncols = N2; a.in_col_stride = d->in_axis_stride;
           a.nb1 = nc; a.in_b1_stride = d->in_col_stride;

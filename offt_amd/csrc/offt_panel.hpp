@@ -196,8 +196,9 @@ struct PassArgs {
   unsigned xcd_gshift;      // log2 G, G = run of neighbouring panels one XCD takes
   double scale;
   const long long *in_tab, *out_tab;  // per-block element offsets (offt_pass_desc::in_block_tab / out_block_tab) or nullptr
-  const void *tw4;          // TW4 kernels (first sub-pass of a four-step line): the exact full-wave table of the LONG length;
+  const void *tw4;          // TW4 kernels (first sub-pass of a four-step line): w^(k1 j2) of the LONG length as a table [k1][j2];
   int tw4_b1;               //   output index k1 of column j2 (tw4_b1 = 0) or of batch entry j2 = b1 (tw4_b1 = 1) times w^(k1 j2)
+  int tw4_n2;               //   row length of that table
 };
 
 template <int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT, typename T>
@@ -517,7 +518,7 @@ fft_panel_k(PassArgs a, const typename vec2<T>::type *in, typename vec2<T>::type
           if constexpr (TW4) {
             // times w^(k1 j2) of the long line, before the conj-out / scale below (for the inverse conj(v w) = conj(v) conj(w))
             const long long jj = a.tw4_b1 ? b1 : (c0 + c);
-            const V2 w = reinterpret_cast<const V2 *>(a.tw4)[(long long)n * jj];
+            const V2 w = reinterpret_cast<const V2 *>(a.tw4)[(long long)n * a.tw4_n2 + jj];
             x = cx<T>{x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
           }
           long long off = (long long)(cn & mask) * a.out_axis;  // uniform
@@ -949,6 +950,10 @@ void reg_variant(int id, int defmask = -1) {
 }
 
 // strided / strided instance with the four-step twiddles on its stores (the first sub-pass of a long line, offt_kernels.hip)
+#ifndef OFFT_TW4_KEEP
+#define OFFT_TW4_KEEP 1
+#endif
+constexpr bool TW4_KEEP = OFFT_TW4_KEEP != 0;  // its stores go to the scratch the second sub-pass reads right away: default cache policy
 template <typename T, int N, int E, int R0, int R1, int R2, int COLS, bool SPLIT>
 void reg_variant_tw4(int id) {
   using Cfg = PanelCfg<N, E, R0, R1, R2, COLS, SPLIT, T>;
@@ -957,7 +962,7 @@ void reg_variant_tw4(int id) {
   snprintf(nm, sizeof nm, "%s N=%d E=%d radix=%dx%dx%d cols=%d four-step twiddles on the stores lds=%zuB", prec ? "f32" : "f64", N, E, R0, R1, R2,
            COLS, (size_t)Cfg::LDS_BYTES);
   registry().push_back(Variant{N, prec, false, false, id, true, false, COLS, Cfg::NT, E, Cfg::LDS_BYTES,
-                               (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT, false, false, true>, nm, false, false, false, nullptr});
+                               (const void *)fft_panel_k<T, N, E, R0, R1, R2, COLS, false, false, SPLIT, false, TW4_KEEP, true>, nm, false, false, false, nullptr});
   registry().back().tw4 = true;
 }
 

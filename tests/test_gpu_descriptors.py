@@ -28,7 +28,7 @@ class Desc(C.Structure):
                 ("in_block_stride", C.c_longlong), ("out_block_stride", C.c_longlong),
                 ("in_block_tab", C.c_void_p), ("out_block_tab", C.c_void_p),
                 ("in_contig", C.c_int), ("out_contig", C.c_int), ("variant", C.c_int), ("scale", C.c_double),
-                ("real_input", C.c_int), ("out_keep", C.c_int), ("no_pairs", C.c_int), ("tw4", C.c_void_p), ("tw4_b1", C.c_int)]
+                ("real_input", C.c_int), ("out_keep", C.c_int), ("no_pairs", C.c_int), ("tw4", C.c_void_p), ("tw4_b1", C.c_int), ("tw4_n2", C.c_int)]
 
 
 def layout(rng, n, ncols, nb1, nb2, split, nfloor, contig):
