@@ -922,9 +922,10 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
 // grid the reference accepts is refused, not to be fast.
 // ---------------------------------------------------------------------------
 struct LongTab { void *chirp = nullptr, *bhat = nullptr; int m = 0; };
-std::map<std::pair<int, int>, LongTab> g_long;  // (guarded by g_blue_mu)
+std::mutex g_long_mu;  // (its own lock: blue_build runs an M-point pass while the Bluestein registry's is held, and every pass looks here)
+std::map<std::pair<int, int>, LongTab> g_long;
 bool long_lookup(int n, int prec, LongTab *out) {
-  std::lock_guard<std::mutex> lk(g_blue_mu);
+  std::lock_guard<std::mutex> lk(g_long_mu);
   auto it = g_long.find(std::make_pair(n, prec));
   if (it == g_long.end()) return false;
   if (out) *out = it->second;
@@ -1101,7 +1102,7 @@ int offt_hipk_prepare(int n, int precision) {
     BlueTab bt;
     const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
     if (!rc) {
-      std::lock_guard<std::mutex> lk(g_blue_mu);
+      std::lock_guard<std::mutex> lk(g_long_mu);
       LongTab lt; lt.chirp = bt.chirp; lt.bhat = bt.bhat; lt.m = bt.m;
       g_long[std::make_pair(n, precision)] = lt;
     }
