@@ -140,6 +140,7 @@ static int world_max(struct _offt_plan *po, double *v);
 static void static_sweep(struct _offt_plan *po, void *user_buf, const struct _offt_params *custom);
 struct hip_state;
 static void slab_teardown(struct hip_state *st);
+static void inv_cache_drop(struct hip_state *st);
 static int slab_setup(struct _offt_plan *po, struct hip_state *st);
 
 #ifdef OFFT_TEST_SEAMS
@@ -450,6 +451,8 @@ typedef struct hip_state {
   int warned_in;
   struct step_list *rec; /* non-NULL: the schedule is being recorded, not run (multi-rank inverse) */
   int rec_tag;           /* ... tag of the steps being recorded (see step) */
+  struct step_list *inv_cache; /* the recorded schedule of the last multi-rank inverse, kept while the plan's buffers, kernels and */
+  const void *inv_data;        /* ... the caller's array stay what they were (inv_cache_drop: re-setup, options, variants) */
 } hip_state;
 
 /* ---- default backend: HIP + RCCL ----------------------------------------- */
@@ -790,6 +793,7 @@ static void p2p_teardown(hip_state *st) {
 /* ------------------------------------------------------------------------- */
 static void ring_teardown(hip_state *st) {
   const offt_backend *be = st->be;
+  inv_cache_drop(st);
   for (int r = 0; r < st->ring; r++) {
     if (st->send1 && !st->recv1_base) be->dfree(st->send1[r]);
     if (st->recv1 && st->recv1 != st->send1 && !st->recv1_base) be->dfree(st->recv1[r]);
@@ -1555,6 +1559,7 @@ int offt_hip_set_exchange(struct _offt_plan *po, int mode) {
 int offt_hip_set_option(struct _offt_plan *po, int option, long long value) {
   hip_state *st = (hip_state *)po->hip_state;
   int rebuild = 0;
+  inv_cache_drop(st);
   switch (option) {
     case OFFT_HIP_OPT_ZGROUP_MIB: st->opt.zgroup_mib = (int)value; break;
     case OFFT_HIP_OPT_ZGROUP_STREAMS: st->opt.zgroup_streams = (int)value; break;
@@ -1606,10 +1611,11 @@ void offt_hip_set_async(struct _offt_plan *po, int async) { ((hip_state *)po->hi
 #if defined(OFFT_TEST_SEAMS) || defined(OFFT_BENCH_DIAGNOSTICS)
 /* diagnostics (compiled into the test build and into builds made with -DOFFT_BENCH_DIAGNOSTICS only): leave out the FFT
  * passes (mask 1) or the exchanges (mask 2) of the multi-rank schedules -- results are meaningless while a mask is set */
-void offt_hip_set_debug_skip(struct _offt_plan *po, int mask) { ((hip_state *)po->hip_state)->skip_mask = mask; }
+void offt_hip_set_debug_skip(struct _offt_plan *po, int mask) { inv_cache_drop((hip_state *)po->hip_state); ((hip_state *)po->hip_state)->skip_mask = mask; }
 #endif
 void offt_hip_set_variant(struct _offt_plan *po, int axis, int variant) {
   if (axis >= 0 && axis < 3) ((hip_state *)po->hip_state)->variant[axis] = variant;
+  inv_cache_drop((hip_state *)po->hip_state);
 }
 double offt_hip_last_device_seconds(const struct _offt_plan *po) { return ((const hip_state *)po->hip_state)->last_dev_s; }
 /* 0, or the two timer slots (bit 0 = z, 1 = y, 2 = x) whose launches alternated and were measured as a pair */
@@ -2061,10 +2067,21 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   const offt_backend *be = st->be;
   void *s = st->s_compute;
   if (po->is_r2c) { SET_ERR("complex-to-real inverse is not built (the reference has no inverse at all)"); return -1; }
-  step_list L = {NULL, 0, 0};
-  st->rec = &L;
-  int rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, -1);
-  st->rec = NULL;
+  /* the forward schedule, recorded: once per (plan state, caller's array) -- a second inverse on the same array replays the
+   * kept list (recording costs the host some 0.1 ms during which the device waits) */
+  int rc = 0;
+  if (!st->inv_cache || st->inv_data != data) {
+    inv_cache_drop(st);
+    st->inv_cache = (step_list *)calloc(1, sizeof(step_list));
+    if (!st->inv_cache) { SET_ERR("out of memory"); return -1; }
+    st->rec = st->inv_cache;
+    rc = st->slab_zyx ? execute_slab(po, data) : execute_pipeline(po, data, -1);
+    st->rec = NULL;
+    st->inv_data = data;
+    if (rc) inv_cache_drop(st);
+  }
+  step_list Lempty = {NULL, 0, 0};
+  const step_list L = st->inv_cache ? *st->inv_cache : Lempty;
   be->event_record(st->evp[0], s);
   const int overlap_slab = st->slab_zyx && st->x1 && !st->p2p && st->sH > 0 && st->ev_sa && st->ev_s1 && st->sNt > 0;
   const int overlap_pencil = !st->slab_zyx && !st->p2p && (st->x1 || st->x2) && st->ntiles > 0 && st->ev_t2 && st->ev_a2 &&
@@ -2137,8 +2154,11 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
   }
   if (!overlap_pencil) { be->event_record(st->evp[1], s); be->event_record(st->evp[2], s); }
   be->event_record(st->evp[3], s);
-  rec_free(&L);
   return rc;
+}
+static void inv_cache_drop(hip_state *st) {
+  if (st->inv_cache) { rec_free(st->inv_cache); free(st->inv_cache); }
+  st->inv_cache = NULL; st->inv_data = NULL;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2173,6 +2193,7 @@ static int execute_inverse_multi(struct _offt_plan *po, void *data) {
 /* ------------------------------------------------------------------------- */
 static void slab_teardown(hip_state *st) {
   const offt_backend *be = st->be;
+  inv_cache_drop(st);
   be->dfree(st->S1); be->dfree(st->R1); be->dfree(st->R2);
   st->S1 = st->R1 = st->R2 = NULL;
   be->dfree(st->tab_s1); st->tab_s1 = NULL;

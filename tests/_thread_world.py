@@ -312,6 +312,10 @@ def main():
                     api.offt_3d_execute(po, dev.data_ptr(), dev.data_ptr())
                     if not np.array_equal(dev.cpu().numpy().view(ct), res["out"] * ct(0.5)):
                         raise RuntimeError("forward after inverse differs from the first transform (times 1/2)")
+                    if case.get("inv") == 2:  # the inverse again, on the same array: the schedule kept from the first one, other data
+                        api.offt_3d_execute_dir(po, dev.data_ptr(), dev.data_ptr(), +1)
+                        if not np.array_equal(cpu_world.input_block(c, dev.cpu().numpy().view(ct)), res["inv"] * ct(0.5)):
+                            raise RuntimeError("second inverse (kept schedule) differs from the first (times 1/2)")
             bar.wait()
             api.offt_3d_fin(po)
             unseam()
@@ -359,6 +363,11 @@ def main():
             bp = back.ctypes.data_as(C.c_void_p)
             api.offt_3d_execute_dir(po, bp, bp, +1)
             res["inv"] = cpu_world.input_block(c, back)
+            if case.get("inv") == 2:  # once more on the SAME array: the plan replays the schedule it kept from the first inverse
+                back[:] = buf
+                api.offt_3d_execute_dir(po, bp, bp, +1)
+                if not np.array_equal(cpu_world.input_block(c, back), res["inv"]):
+                    raise RuntimeError("second inverse (kept schedule) differs from the first")
             if case.get("repeat"):
                 b2 = fill()
                 p2 = b2.ctypes.data_as(C.c_void_p)

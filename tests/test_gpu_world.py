@@ -226,8 +226,8 @@ def test_staged_exchange_with_an_asynchronous_transport(built, tmp_path):
     # world in which tools/async_negative_control.sh sees a dropped edge ("K2 waits for its chunk") as a wrong result
     # (profiles/r03_async_negative_control.txt; in an 8-thread world the slow host rendezvous hides it)
     run_thread_world(2, [dict(N=[256, 256, 256], params=dict(P1=1), repeat=2, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=2), repeat=2, **{"async": 1}),
-                         dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=8), inv=1, repeat=1, **{"async": 1}),
-                         dict(N=[256, 128, 256], params=dict(P1=2, T1=16, W1=1, T2=16), inv=1, repeat=1, **{"async": 1}),
+                         dict(N=[256, 256, 256], params=dict(P1=1, T1=32, T2=8), inv=2, repeat=1, **{"async": 1}),
+                         dict(N=[256, 128, 256], params=dict(P1=2, T1=16, W1=1, T2=16), inv=2, repeat=1, **{"async": 1}),
                          dict(N=[256, 256, 256], params=dict(P1=1, S=1, T1=16, W1=1, T2=16), inv=1, repeat=1, **{"async": 1}),
                          dict(N=[256, 256, 256], params=dict(P1=1, S=1), repeat=1, **{"async": 1}), dict(N=[256, 256, 256], params=dict(P1=1), f32=1, repeat=1, **{"async": 1})], tmp_path)
     # the other half: a FAST wire ("async": 2) and SLOW passes (the test build holds the stream 50 ms ahead of every pass), so

@@ -26,14 +26,14 @@ def run_cpu_thread_world(size, cases, tmp_path):
 
 def test_staged_exchange_in_a_thread_world(built, tmp_path):
     """the thread world itself (staged exchange through the in-process wire), slab and pencil"""
-    run_cpu_thread_world(2, [dict(N=[8, 8, 8], params=dict(P1=1)), dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=2), inv=1)], tmp_path)
+    run_cpu_thread_world(2, [dict(N=[8, 8, 8], params=dict(P1=1)), dict(N=[8, 8, 8], params=dict(P1=2, T1=2, T2=2), inv=2)], tmp_path)
 
 
 def test_direct_store_two_ranks(built, tmp_path):
     cases = [dict(N=[8, 8, 8], params=dict(P1=1), p2p=1), dict(N=[8, 8, 8], params=dict(P1=2), p2p=1),
              dict(N=[8, 8, 8], params=dict(P1=1, T1=2, T2=2), p2p=1, repeat=2),
-             dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2), p2p=1, inv=1, repeat=1),          # ragged tiles and chunks
-             dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3), p2p=1, inv=1, repeat=2),          # pencil, uneven blocks
+             dict(N=[10, 6, 9], params=dict(P1=1, T1=3, T2=2), p2p=1, inv=2, repeat=1),          # ragged tiles and chunks
+             dict(N=[9, 7, 11], params=dict(P1=2, T1=2, T2=3), p2p=1, inv=2, repeat=2),          # pencil, uneven blocks
              dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=1, T2=2), p2p=1, repeat=3),            # ring of 2 slots reused
              dict(N=[8, 8, 8], params=dict(P1=2, T1=2, W1=0), p2p=1, repeat=2),                  # ring of 1
              dict(N=[8, 8, 8], params=dict(P1=1, S=1, T1=2, W1=1), p2p=1, inv=1),                # x-y-z layout: pencil schedule on 1 x p
