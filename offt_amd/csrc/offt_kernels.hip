@@ -1098,7 +1098,7 @@ int offt_hipk_prepare(int n, int precision) {
   }
   // ... and a length without a split becomes a Bluestein convolution on lines of M = 2^k >= 2n - 1 points through scratch
   static const bool long_on = !(getenv("OFFT_BLUESTEIN_LONG") && atoi(getenv("OFFT_BLUESTEIN_LONG")) == 0);
-  if (no_direct && !four_lookup(n, precision, nullptr) && long_on && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
+  if (no_direct && !four_lookup(n, precision, nullptr) && long_on && four_on /* (its M-point lines need the four-step path) */ && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
     BlueTab bt;
     const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
     if (!rc) {
