@@ -118,8 +118,9 @@ def test_mixed_radix_register_kernel(built, shape):
         check64(got, want)
 
 
-@pytest.mark.parametrize("shape", [(432, 6, 10), (10, 6, 1296), (1728, 4, 2), (324, 324, 8), (2500, 2, 4), (6, 2187, 2), (4, 4, 3528),
-                                   (1088, 4, 2), (6, 608, 2), (4, 4, 992), (2, 2, 1334)])  # 17*64, 19*32, 31*32, 2*23*29
+# (every shape compiles a kernel at plan time, 10-15 s each: 1296, 2500 and 608 = 19*32 were dropped from the list to keep the tier short)
+@pytest.mark.parametrize("shape", [(432, 6, 10), (1728, 4, 2), (324, 324, 8), (6, 2187, 2), (4, 4, 3528),
+                                   (1088, 4, 2), (4, 4, 992), (2, 2, 1334)])  # 17*64, 31*32, 2*23*29
 def test_plan_time_specialised_kernel(built, shape):
     """a 31-smooth length of 256 .. 4096 points without a precompiled panel kernel: offt_3d_init has hipRTC compile
     fft_panelx_k for it (offt_hipk_prepare); same tolerances, every layout, f32 too"""
