@@ -1062,6 +1062,7 @@ int offt_hipk_prepare(int n, int precision) {
   if ((no_direct || n == 8192) && four_on && !four_lookup(n, precision, nullptr)) {
     int best1 = 0;
     double best_score = 1e30;
+    const int forced_n1 = getenv("OFFT_FOURSTEP_N1") ? atoi(getenv("OFFT_FOURSTEP_N1")) : 0;
     for (int n1 = 2; (long long)n1 * n1 <= n; ++n1) {
       if (n % n1) continue;
       const int n2 = n / n1;
@@ -1072,15 +1073,19 @@ int offt_hipk_prepare(int n, int precision) {
       double score = std::log((double)n2 / (double)n1);
       if (!f1) score += 4.0;
       if (!f2) score += 4.0;
-      // ... except that a SHORT first sub-pass wins when the other factor still has a register kernel: 32 points in single,
-      // 64 in double precision -- few points per line, 64 (8) unit-stride columns per workgroup and the twiddles on its stores.
-      // Swept over 8192 / 16384 / 32768 points (profiles/r03_four_step.txt): single precision 8192 = 32 x 256 at 37.5 % of
-      // the roofline against 31.9 % (64 x 128) and 28.8 % (128 x 64); double 64 x 128 at 37.3 % against 36.4 % (32 x 256)
-      const int pref = precision == OFFT_PREC_F64 ? 64 : 32;
-      if ((n1 == pref || (n1 == 32 && n % pref)) && f2 && find_variant(n1, precision, false, false, -1, false, false, true)) score = n1 == pref ? -2.0 : -1.0;
+      // ... except that a SHORT first sub-pass with the twiddles on its stores wins when the other factor still has a register
+      // kernel: few points per line, one thread per line on 64 unit-stride columns (8 columns at 64 points).  Order of
+      // preference, from sweeps over 8192 / 16384 / 32768 / 6000 / 10000 / 12000 points (profiles/r03_four_step.txt):
+      //   double  64 (8192 = 64 x 128: 37.3 % of the roofline, 36.4 % for 32 x 256), then 16, 8, 4 (6000 = 16 x 375: 31.5 %, 10000 =
+      //           16 x 625: 31.6 %, both 17-18 % as balanced unfused splits; 12000 = 16 x 750: 26.7 %, 20.1 % for 32 x 375), 32, 2
+      //   single  32 (8192 = 32 x 256: 37.5 %, 31.9 % for 64 x 128), then 16, 8, 4, 2
+      static const int pref64[] = {64, 16, 8, 4, 32, 2, 0}, pref32[] = {32, 16, 8, 4, 2, 0};
+      const int *pref = precision == OFFT_PREC_F64 ? pref64 : pref32;
+      for (int r = 0; pref[r]; ++r)
+        if (n1 == pref[r] && f2 && find_variant(n1, precision, false, false, -1, false, false, true)) score = -10.0 + 0.1 * r;
+      if (forced_n1 == n1) score = -100.0;  // (OFFT_FOURSTEP_N1, for sweeps: only among the splits that are possible at all)
       if (score < best_score) { best_score = score; best1 = n1; }
     }
-    if (getenv("OFFT_FOURSTEP_N1") && atoi(getenv("OFFT_FOURSTEP_N1")) > 1 && n % atoi(getenv("OFFT_FOURSTEP_N1")) == 0) best1 = atoi(getenv("OFFT_FOURSTEP_N1"));
     if (best1 && (offt_hipk_prepare(best1, precision) || offt_hipk_prepare(n / best1, precision) ||
                   !direct_ok(best1, precision) || !direct_ok(n / best1, precision)))
       best1 = 0;
