@@ -1081,8 +1081,11 @@ int offt_hipk_prepare(int n, int precision) {
       //   single  32 (8192 = 32 x 256: 37.5 %, 31.9 % for 64 x 128), then 16, 8, 4, 2
       static const int pref64[] = {64, 16, 8, 4, 32, 2, 0}, pref32[] = {32, 16, 8, 4, 2, 0};
       const int *pref = precision == OFFT_PREC_F64 ? pref64 : pref32;
+      // (second choice, behind every split whose long factor is precompiled: a long factor that gets its kernel compiled NOW --
+      //  seconds of plan time for 10000 = 16 x 625 at 32 % instead of 100 x 100 at 18 %)
+      const bool rtc2 = !f2 && rtc_enabled() && n2 >= 256 && n2 <= 4096 && smooth13(n2);
       for (int r = 0; pref[r]; ++r)
-        if (n1 == pref[r] && f2 && find_variant(n1, precision, false, false, -1, false, false, true)) score = -10.0 + 0.1 * r;
+        if (n1 == pref[r] && (f2 || rtc2) && find_variant(n1, precision, false, false, -1, false, false, true)) score = (f2 ? -10.0 : -5.0) + 0.1 * r;
       if (forced_n1 == n1) score = -100.0;  // (OFFT_FOURSTEP_N1, for sweeps: only among the splits that are possible at all)
       if (score < best_score) { best_score = score; best1 = n1; }
     }
