@@ -828,7 +828,7 @@ int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 // stays a 128-B segment.  For a strided-in pass step A writes S'[k1][j2][column] and T transposes on the way.
 // Three sweeps over the data instead of one: a correctness net with decent bandwidth, not a tuned path.
 // ---------------------------------------------------------------------------
-struct FourStep { int n1 = 0, n2 = 0; void *t4 = nullptr; };  // t4[k1][j2] = w_n^(k1 j2), from the exact full-wave table
+struct FourStep { int n1 = 0, n2 = 0; void *t4 = nullptr; bool all = false; };  // all: every flavour goes this way (no register kernel for n)  // t4[k1][j2] = w_n^(k1 j2), from the exact full-wave table
 std::mutex g_four_mu;
 std::map<std::pair<int, int>, FourStep> g_four;
 struct Scratch { void *p[3] = {nullptr, nullptr, nullptr}; size_t bytes[3] = {0, 0, 0}; };  // 0, 1: four-step; 2: lines through scratch
@@ -1059,7 +1059,11 @@ int offt_hipk_prepare(int n, int precision) {
   const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
   const bool no_direct = !find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024;
   static const bool four_on = !(getenv("OFFT_FOURSTEP") && atoi(getenv("OFFT_FOURSTEP")) == 0);
-  if ((no_direct || n == 8192) && four_on && !four_lookup(n, precision, nullptr)) {
+  // ... and so does a length above the plan-time kernels' range that would otherwise run on the any-length kernel (4800, 5000;
+  // in single precision up to 10240 points: 10000 at 15 % of the roofline there) -- if it has a FUSED split (score < 0 below)
+  BlueTab bt_any;
+  const bool any_only = !no_direct && n > 4096 && !find_variant(n, precision, true, true, -1) && !blue_lookup(n, precision, &bt_any);
+  if ((no_direct || n == 8192 || any_only) && four_on && !four_lookup(n, precision, nullptr)) {
     int best1 = 0;
     double best_score = 1e30;
     const int forced_n1 = getenv("OFFT_FOURSTEP_N1") ? atoi(getenv("OFFT_FOURSTEP_N1")) : 0;
@@ -1089,11 +1093,13 @@ int offt_hipk_prepare(int n, int precision) {
       if (forced_n1 == n1) score = -100.0;  // (OFFT_FOURSTEP_N1, for sweeps: only among the splits that are possible at all)
       if (score < best_score) { best_score = score; best1 = n1; }
     }
+    if (any_only && best_score >= 0.0) best1 = 0;  // (unfused, three sweeps: the any-length kernel is no worse)
     if (best1 && (offt_hipk_prepare(best1, precision) || offt_hipk_prepare(n / best1, precision) ||
                   !direct_ok(best1, precision) || !direct_ok(n / best1, precision)))
       best1 = 0;
     if (best1) {
       FourStep fs; fs.n1 = best1; fs.n2 = n / best1;
+      fs.all = !find_variant(n, precision, true, true, -1);
       HIPK_CHECK(hipMalloc(&fs.t4, (size_t)n * esz));
       (void)hipGetLastError();
       if (precision == OFFT_PREC_F64) hipLaunchKernelGGL(four_table_k<double2>, dim3((n + 255) / 256), dim3(256), 0, nullptr, (double2 *)fs.t4, (const double2 *)tb.full, n, fs.n2);
@@ -1138,7 +1144,11 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
     if (four_lookup(d->n, d->precision, &fs)) {
       const size_t esz4 = d->precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
       const bool no_direct = !find_variant(d->n, d->precision, true, true, -1) && 2 * (size_t)d->n * esz4 > (size_t)160 * 1024;
-      if (no_direct || !(d->in_contig && d->out_contig)) return four_pass(d, in, out, stream, fs);
+      // a length the any-length kernel could take as well stays there for what the decomposition does not follow: real
+      // input, per-peer blocks that are not whole runs of n2 inputs / n1 outputs
+      const bool follows = !d->real_input && !(d->in_split && (d->in_split_nfloor || d->in_split % fs.n2)) &&
+                           !(d->out_split && (d->out_split_nfloor || d->out_split % fs.n1));
+      if (no_direct || (fs.all ? follows : !(d->in_contig && d->out_contig))) return four_pass(d, in, out, stream, fs);
     }
     LongTab lt;
     if (long_lookup(d->n, d->precision, &lt)) return long_pass(d, in, out, stream, lt);

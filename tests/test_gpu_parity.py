@@ -406,7 +406,9 @@ def test_full_size_1024_single_precision_full_grid_vs_double(built):
 
 @pytest.mark.parametrize("shape,prec,kw", [((8, 8, 6000), api.F64, {}), ((16384, 4, 4), api.F64, {}), ((4, 12000, 4), api.F32, {}),
                                            ((8, 6000, 8), api.F64, dict(S=1)), ((8, 8, 16384), api.F32, dict(S=1)),
-                                           ((8192, 8, 8), api.F64, {}), ((8, 8192, 8), api.F64, dict(S=1)), ((8, 8, 8192), api.F32, {})])
+                                           ((8192, 8, 8), api.F64, {}), ((8, 8192, 8), api.F64, dict(S=1)), ((8, 8, 8192), api.F32, {}),
+                                           # lengths the any-length kernel could take, routed here because they have a fused split
+                                           ((8, 8, 5000), api.F64, {}), ((4, 10000, 4), api.F32, {}), ((4800, 4, 4), api.F64, dict(S=1))])
 def test_long_lines_four_step(built, shape, prec, kw):
     """lines no single kernel takes (above 5120 double / 10240 single points; FFTW plans any N, offt-compute.c:335-341,
     416-425) run as a four-step decomposition n = n1 n2 -- two sub-passes of the library's own kernels and a twiddle sweep
