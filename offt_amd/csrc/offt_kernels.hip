@@ -831,7 +831,18 @@ int log2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 struct FourStep { int n1 = 0, n2 = 0; void *t4 = nullptr; bool all = false; };  // all: every flavour goes this way (no register kernel for n)  // t4[k1][j2] = w_n^(k1 j2), from the exact full-wave table
 std::mutex g_four_mu;
 std::map<std::pair<int, int>, FourStep> g_four;
-struct Scratch { void *p[3] = {nullptr, nullptr, nullptr}; size_t bytes[3] = {0, 0, 0}; };  // 0, 1: four-step; 2: lines through scratch
+// scratch per caller stream and per NESTING DEPTH of the decomposing paths: a four-step line whose sub-pass goes through scratch
+// lines (a real-input line gathered as complex; a factor that runs as a Bluestein convolution), whose power-of-two lines are
+// four-step lines again ... every level keeps its own buffers while the levels below it run.  Slots 3 d + {0, 1}: four-step of
+// depth d, 3 d + 2: lines through scratch of depth d
+enum { SCRATCH_DEPTHS = 4 };
+struct Scratch { void *p[3 * SCRATCH_DEPTHS] = {}; size_t bytes[3 * SCRATCH_DEPTHS] = {}; };
+thread_local int g_scratch_depth = 0;
+struct DepthGuard {
+  int d;
+  DepthGuard() : d(g_scratch_depth++) {}
+  ~DepthGuard() { --g_scratch_depth; }
+};
 std::map<void *, Scratch> g_four_scratch;  // per stream
 
 bool four_lookup(int n, int prec, FourStep *out) {
@@ -1059,10 +1070,11 @@ int offt_hipk_prepare(int n, int precision) {
   const size_t esz = precision == OFFT_PREC_F64 ? sizeof(double2) : sizeof(float2);
   const bool no_direct = !find_variant(n, precision, true, true, -1) && 2 * (size_t)n * esz > (size_t)160 * 1024;
   static const bool four_on = !(getenv("OFFT_FOURSTEP") && atoi(getenv("OFFT_FOURSTEP")) == 0);
-  // ... and so does a length above the plan-time kernels' range that would otherwise run on the any-length kernel (4800, 5000;
-  // in single precision up to 10240 points: 10000 at 15 % of the roofline there) -- if it has a FUSED split (score < 0 below)
+  // ... and so does a length that would otherwise run on the any-length kernel -- above the plan-time kernels' range (4800,
+  // 5000; in single precision up to 10240 points: 10000 at 15 % of the roofline there) or above the Bluestein panel kernel's with
+  // a large prime factor (4076 = 4 x 1019) -- if it has a FUSED split (score < 0 below)
   BlueTab bt_any;
-  const bool any_only = !no_direct && n > 4096 && !find_variant(n, precision, true, true, -1) && !blue_lookup(n, precision, &bt_any);
+  const bool any_only = !no_direct && n > 2048 && !find_variant(n, precision, true, true, -1) && !blue_lookup(n, precision, &bt_any);
   if ((no_direct || n == 8192 || any_only) && four_on && !four_lookup(n, precision, nullptr)) {
     int best1 = 0;
     double best_score = 1e30;
@@ -1088,8 +1100,18 @@ int offt_hipk_prepare(int n, int precision) {
       // (second choice, behind every split whose long factor is precompiled: a long factor that gets its kernel compiled NOW --
       //  seconds of plan time for 10000 = 16 x 625 at 32 % instead of 100 x 100 at 18 %)
       const bool rtc2 = !f2 && rtc_enabled() && n2 >= 256 && n2 <= 4096 && smooth13(n2);
+      // (third: a long factor with a prime factor > 13 that runs on the Bluestein panel kernel -- 4076 = 4 x 1019)
+      int maxp2 = 1;
+      { int m = n2; for (int p = 2; p * p <= m; ++p) while (m % p == 0) { maxp2 = p > maxp2 ? p : maxp2; m /= p; } if (m > maxp2) maxp2 = m; }
+      const bool blue2 = !f2 && !rtc2 && blue_enabled() && n2 >= 32 && n2 <= 2048 && maxp2 > 13 && find_blue(blue_m(n2), precision, true, false) != nullptr &&
+                         find_blue(blue_m(n2), precision, false, false) != nullptr;
       for (int r = 0; pref[r]; ++r)
-        if (n1 == pref[r] && (f2 || rtc2) && find_variant(n1, precision, false, false, -1, false, false, true)) score = (f2 ? -10.0 : -5.0) + 0.1 * r;
+        if (n1 == pref[r] && (f2 || rtc2 || blue2) && find_variant(n1, precision, false, false, -1, false, false, true))
+          score = (f2 ? -10.0 : rtc2 ? -5.0 : -3.0) + 0.1 * r;
+      // a factor that would itself go through scratch lines (or the any-length kernel with a radix of hundreds) is a last resort
+      { int mp1 = 1, m = n1; for (int p = 2; p * p <= m; ++p) while (m % p == 0) { mp1 = p > mp1 ? p : mp1; m /= p; } if (m > mp1) mp1 = m;
+        if (!f1 && mp1 > 61 && !(n1 <= 2048 && blue_enabled())) score += 8.0; }
+      if (!f2 && !rtc2 && !blue2 && maxp2 > 61 && !(n2 <= 2048 && blue_enabled())) score += 8.0;
       if (forced_n1 == n1) score = -100.0;  // (OFFT_FOURSTEP_N1, for sweeps: only among the splits that are possible at all)
       if (score < best_score) { best_score = score; best1 = n1; }
     }
@@ -1112,7 +1134,9 @@ int offt_hipk_prepare(int n, int precision) {
   }
   // ... and a length without a split becomes a Bluestein convolution on lines of M = 2^k >= 2n - 1 points through scratch
   static const bool long_on = !(getenv("OFFT_BLUESTEIN_LONG") && atoi(getenv("OFFT_BLUESTEIN_LONG")) == 0);
-  if (no_direct && !four_lookup(n, precision, nullptr) && long_on && four_on /* (its M-point lines need the four-step path) */ && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
+  // (also a length the any-length kernel COULD take, but only with a radix of hundreds -- r multiply-adds per output: 3057 =
+  //  3 x 1019 points ran at 0.6 % of the roofline there)
+  if ((no_direct || (any_only && maxp > 61)) && !four_lookup(n, precision, nullptr) && long_on && four_on /* (its M-point lines need the four-step path) */ && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
     BlueTab bt;
     const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
     if (!rc) {
@@ -1312,8 +1336,10 @@ int four_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
   if ((size_t)cc * N > cap) { cc = (int)(cap / N); if (cc < 1) cc = 1; cb1 = 1; }
   else { const size_t fit = cap / ((size_t)cc * N); if ((size_t)cb1 > fit) cb1 = (int)(fit < 1 ? 1 : fit); }
   const size_t sbytes = (size_t)cc * cb1 * N * esz;
-  char *S = (char *)four_scratch(stream, 0, sbytes);
-  char *Sp = inL ? nullptr : (char *)four_scratch(stream, 1, sbytes);
+  const DepthGuard depth;
+  if (depth.d >= SCRATCH_DEPTHS) { snprintf(g_err, sizeof g_err, "four-step path: decomposition nested too deep for n=%d", N); return -1; }
+  char *S = (char *)four_scratch(stream, 3 * depth.d + 0, sbytes);
+  char *Sp = inL ? nullptr : (char *)four_scratch(stream, 3 * depth.d + 1, sbytes);
   if (!S || (!inL && !Sp)) { snprintf(g_err, sizeof g_err, "four-step path: cannot allocate %zu bytes of scratch", sbytes); return -1; }
   for (int b2 = 0; b2 < d->nb2; ++b2)
     for (int b10 = 0; b10 < d->nb1; b10 += cb1)
@@ -1417,7 +1443,9 @@ int long_pass(const offt_pass_desc *d, const void *in, void *out, void *stream, 
   long long per = (long long)(((size_t)256 << 20) / ((size_t)M * esz));
   if (per < 1) per = 1;
   if (per > nlines) per = nlines;
-  char *U = (char *)four_scratch(stream, 2, (size_t)per * M * esz);
+  const DepthGuard depth;
+  if (depth.d >= SCRATCH_DEPTHS) { snprintf(g_err, sizeof g_err, "lines of %d points through scratch: decomposition nested too deep", N); return -1; }
+  char *U = (char *)four_scratch(stream, 3 * depth.d + 2, (size_t)per * M * esz);
   if (!U) { snprintf(g_err, sizeof g_err, "lines of %d points through scratch: cannot allocate %zu bytes", N, (size_t)per * M * esz); return -1; }
   // the M-point transforms of the scratch lines: contiguous lines, in place
   offt_pass_desc f;

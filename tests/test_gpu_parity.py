@@ -408,7 +408,8 @@ def test_full_size_1024_single_precision_full_grid_vs_double(built):
                                            ((8, 6000, 8), api.F64, dict(S=1)), ((8, 8, 16384), api.F32, dict(S=1)),
                                            ((8192, 8, 8), api.F64, {}), ((8, 8192, 8), api.F64, dict(S=1)), ((8, 8, 8192), api.F32, {}),
                                            # lengths the any-length kernel could take, routed here because they have a fused split
-                                           ((8, 8, 5000), api.F64, {}), ((4, 10000, 4), api.F32, {}), ((4800, 4, 4), api.F64, dict(S=1))])
+                                           ((8, 8, 5000), api.F64, {}), ((4, 10000, 4), api.F32, {}), ((4800, 4, 4), api.F64, dict(S=1)),
+                                           ((8, 8, 4076), api.F64, {}), ((4, 4076, 4), api.F32, dict(S=1))])  # 4 x 1019: the long factor on the Bluestein panel kernel
 def test_long_lines_four_step(built, shape, prec, kw):
     """lines no single kernel takes (above 5120 double / 10240 single points; FFTW plans any N, offt-compute.c:335-341,
     416-425) run as a four-step decomposition n = n1 n2 -- two sub-passes of the library's own kernels and a twiddle sweep
@@ -422,6 +423,11 @@ def test_long_lines_four_step(built, shape, prec, kw):
 
 
 @pytest.mark.parametrize("shape,prec,r2c,kw", [((8, 8, 10007), api.F64, 0, {}), ((4, 20011, 4), api.F32, 0, {}), ((10007, 4, 4), api.F64, 0, dict(S=1)),
+                                               ((8, 8, 3057), api.F64, 0, {}), ((4, 3057, 4), api.F32, 0, dict(S=1)),  # 3 x 1019: the any-length kernel's radix would be 1019
+                                               ((4, 4, 3057 * 2), api.F64, 1, {}),
+                                               # 2 x 3061 (prime): a four-step line whose long factor goes through scratch lines itself -- and, with real
+                                               # input, is gathered into scratch lines first: three levels of scratch, each with its own buffers
+                                               ((4, 4, 6122), api.F64, 1, {}), ((4, 6122, 4), api.F64, 0, {}),
                                                ((8, 8, 6000), api.F64, 1, {}), ((4, 4, 16384), api.F32, 1, {}), ((4, 4, 10007), api.F64, 1, {})])
 def test_long_lines_through_scratch(built, shape, prec, r2c, kw):
     """what the four-step decomposition leaves: a long PRIME line (no n1 n2 to decompose along) runs as a Bluestein
