@@ -705,10 +705,26 @@ bool blue_lookup(int n, int prec, BlueTab *out) {
   return true;
 }
 
+// convolution length of a Bluestein line through scratch (long_pass): not the next power of two -- up to twice 2n - 1 -- but
+// the shortest M >= 2n - 1 of the form (64 | 32) x L, L a precompiled register length: a fused four-step line (10007 points:
+// M = 20480 instead of 32768).  0: none found, use the power of two
+int blue_m_long(int n, int prec) {
+  const long long need = 2LL * n - 1;
+  const int n1 = prec == OFFT_PREC_F64 ? 64 : 32;
+  if (!find_variant(n1, prec, false, false, -1, false, false, true)) return 0;
+  long long best = 0;
+  for (auto &v : registry()) {
+    if (v.prec != prec || !v.inc || !v.outc || v.r2c || v.tw4 || v.id != 0 || v.n < 64 || v.n > 4096) continue;
+    const long long m = (long long)n1 * v.n;
+    if (m >= need && m < (1LL << 24) && (!best || m < best)) best = m;
+  }
+  return best && best < blue_m(n) ? (int)best : 0;
+}
+
 template <typename T>
-int blue_build(int n, int prec, BlueTab &tb) {
+int blue_build(int n, int prec, BlueTab &tb, int m_override = 0) {
   using V2 = typename vec2<T>::type;
-  const int m = blue_m(n);
+  const int m = m_override ? m_override : blue_m(n);
   const long double pi = 3.14159265358979323846264338327950288419716939937510L;
   // angle pi k^2 / n with k^2 reduced mod 2n in integers: exact argument reduction
   auto ang = [&](long long k) { return pi * (long double)((k * k) % (2LL * n)) / (long double)n; };
@@ -1138,7 +1154,9 @@ int offt_hipk_prepare(int n, int precision) {
   //  3 x 1019 points ran at 0.6 % of the roofline there)
   if ((no_direct || (any_only && maxp > 61)) && !four_lookup(n, precision, nullptr) && long_on && four_on /* (its M-point lines need the four-step path) */ && blue_enabled() && n < (1 << 24) && !long_lookup(n, precision, nullptr)) {
     BlueTab bt;
-    const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt) : blue_build<float>(n, precision, bt);
+    static const bool short_m = !(getenv("OFFT_BLUESTEIN_LONG_POW2") && atoi(getenv("OFFT_BLUESTEIN_LONG_POW2")) != 0);
+    const int mlong = short_m ? blue_m_long(n, precision) : 0;
+    const int rc = precision == OFFT_PREC_F64 ? blue_build<double>(n, precision, bt, mlong) : blue_build<float>(n, precision, bt, mlong);
     if (!rc) {
       std::lock_guard<std::mutex> lk(g_long_mu);
       LongTab lt; lt.chirp = bt.chirp; lt.bhat = bt.bhat; lt.m = bt.m;
