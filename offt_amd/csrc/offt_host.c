@@ -387,6 +387,7 @@ typedef struct hip_state {
   int t1_custom, t2_custom; /* the caller fixed T1 / T2 (run-fft -T / -t): use them as given */
   int sT, sTz, sNt, sH;  /* slab schedule: x-tile, z-chunk thickness, #tiles, #chunks */
   int slab_yc;           /* slab blocks laid out [chunk][x_t][z in chunk][y] (y contiguous), see execute_slab() */
+  int slab_inplace;      /* K2 stores its y-transformed chunk straight into the caller's array and K3 runs in place: no R2 volume */
   size_t sblkS;          /* elements per (tile, peer) block of S1 / R1: [z_l][y][x_t] */
   size_t sBc;            /* y-contiguous layout: pitch of a (peer, chunk) block = all its tiles + a de-aliasing pad (slab_setup) */
   void *S1, *R1, *R2;    /* packed send volume, receive volume (same layout), y-transformed volume */
@@ -2239,8 +2240,14 @@ static int slab_setup(struct _offt_plan *po, hip_state *st) {
   const size_t vol = (st->slab_yc ? st->sBc * st->sH : st->sblkS * st->sNt) * c->p2;
   /* (direct-store exchange: no send volume -- K1 stores into the peers' R1, its own block into its own) */
   if (!(st->p2p && st->x1)) st->S1 = be->dmalloc(vol * st->esz);
-  st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
-  if ((!st->S1 && !(st->p2p && st->x1)) || !st->R2) return -1;
+  /* the y-transformed volume [z_l][y][x] has the strides of the caller's z-y-x output: K2(h) stores its chunk straight into
+   * the caller's array (every FFTz has read its input by then -- the K1 phase precedes the chunks on the compute stream) and
+   * K3(h) transforms the x-lines in place.  One volume less per rank: send + receive volumes and the caller's array, the
+   * receive volume alone with the direct-store exchange.  (OFFT_SLAB_R2=1: the separate volume of rounds 1-2) */
+  st->slab_inplace = c->ostride[0] == 1 && c->ostride[1] == c->M1 && c->ostride[2] == (long long)c->M4 * c->M1 &&
+                     !(getenv("OFFT_SLAB_R2") && atoi(getenv("OFFT_SLAB_R2")));
+  if (!st->slab_inplace) st->R2 = be->dmalloc((size_t)c->M3 * c->M4 * c->M1 * st->esz);
+  if ((!st->S1 && !(st->p2p && st->x1)) || (!st->R2 && !st->slab_inplace)) return -1;
   if (st->x1) {
     st->R1 = be->dmalloc(vol * st->esz);
     if (!st->R1) return -1;
@@ -2384,7 +2391,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
         d.out_axis_stride = c->M1; d.out_col_stride = 1; d.out_b1_stride = (long long)c->M4 * c->M1; d.out_b2_stride = T;
         d.out_keep = 1; /* K3(h) reads this chunk of R2 right away: keep it in the Infinity Cache (see execute_single) */
         if (run_pass(st, &d, src + (st->slab_yc ? (size_t)first * c->M2 * Tz * T : (size_t)first * p2 * blk) * esz,
-                     (char *)st->R2 + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s, 0)) return -1;
+                     (char *)(st->slab_inplace ? data : st->R2) + ((size_t)z0 * c->M4 * c->M1 + (size_t)first * T) * esz, s, 0)) return -1;
       }
     }
     /* ---- K3(h): FFTx (offt-compute.c:2729-2730) on whole lines, into the caller's z-y-x layout ---- */
@@ -2397,7 +2404,7 @@ static int execute_slab(struct _offt_plan *po, void *data) {
       d.scale = st->out_scale;
       /* (K3(h) on a second stream, so that K2(h + 1) shares the chip with it, was tried: 1.439 against 1.443 ms for the
        *  chunked phase at 1024^3 on 8 ranks -- nothing; profiles/r03_rehearse_k3_stream.txt) */
-      if (run_pass(st, &d, (char *)st->R2 + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
+      if (run_pass(st, &d, (char *)(st->slab_inplace ? data : st->R2) + (size_t)z0 * c->M4 * c->M1 * esz, (char *)data + (size_t)z0 * c->ostride[2] * esz, s, 0)) return -1;
     }
   }
   st->rec_tag = -1;
