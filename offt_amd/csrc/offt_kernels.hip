@@ -1202,6 +1202,14 @@ int offt_hipk_fft_pass(const offt_pass_desc *d, const void *in, void *out, void 
   BlueTab bt;
   BlueVariant *bv = nullptr;
   if (!v && !d->real_input && blue_lookup(d->n, d->precision, &bt)) bv = find_blue(bt.m, d->precision, d->in_contig != 0, d->out_contig != 0);
+  // a REAL-input line of a Bluestein length: gathered as complex lines into scratch, transformed there by the Bluestein
+  // panel kernel, the first n/2 + 1 outputs scattered -- three sweeps, against a radix of the size of its largest prime
+  // factor on the any-length kernel (OFFT_R2C_BLUESTEIN=0: that kernel, as in rounds 1-2)
+  static const bool r2c_blue = !(getenv("OFFT_R2C_BLUESTEIN") && atoi(getenv("OFFT_R2C_BLUESTEIN")) == 0);
+  if (!v && d->real_input && r2c_blue && blue_lookup(d->n, d->precision, &bt) && find_blue(bt.m, d->precision, true, true)) {
+    LongTab plain;
+    return long_pass(d, in, out, stream, plain);
+  }
   if (v || bv) {
     PassArgs a;
     const int cols = v ? v->cols : bv->cols;
