@@ -203,7 +203,8 @@ def test_long_lines_in_worlds(built, tmp_path):
     length whose uneven per-peer blocks the decomposition cannot follow (6250 over 3: through scratch as well), a long
     real-input line; forward against numpy and the oracle, mirrored inverse"""
     run_thread_world(3, [dict(N=[4, 6, 10007], params=dict(P1=1), inv=1), dict(N=[6, 10007, 4], params=dict(P1=3)),
-                         dict(N=[4, 6, 6250], params=dict(P1=1), inv=1), dict(N=[6, 4, 12000], params=dict(P1=1), r2c=1)], tmp_path)
+                         dict(N=[4, 6, 6250], params=dict(P1=1), inv=1), dict(N=[6, 4, 12000], params=dict(P1=1), r2c=1),
+                         dict(N=[6, 4, 2038], params=dict(P1=1), r2c=1), dict(N=[6, 6, 1016], params=dict(P1=3), r2c=1)], tmp_path)  # real input along Bluestein lengths
 
 
 def test_staged_exchange_with_an_asynchronous_transport(built, tmp_path):
